@@ -1,0 +1,303 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X FFT engine (BASELINE.json metric).
+
+A "step" is ONE pass of the hot path over one batch of synthetic input: a
+batched 1D complex-to-complex forward FFT of `batch` transforms of length `n`,
+device-resident (inputs are already in HBM when the timed region starts),
+executed through the C ABI (fft_gpu_execute_ptr on a plan from
+fft_gpu_plan_1d_ex).  Default workload = BASELINE.json configs[2], the one the
+north-star target is quoted on: N = 1048576 fp32 complex, batch = 512 per GPU.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+N > 1: one process per GPU, the batch is sharded by batch index (each rank owns
+`batch` whole transforms -> weak scaling), there is NO data-path collective;
+torch.distributed (RCCL) is used only for the barriers around the timed region
+and the max-over-ranks of the elapsed time.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "fft-implementation-in-c_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW"
+
+WORKLOADS = {
+    # name: (n, batch per GPU, dtype, description)
+    "1m": (1 << 20, 512, "f32", "N=1048576 fp32 complex, batch=512 per GPU (BASELINE configs[2], north-star)"),
+    "64k": (1 << 16, 4096, "f32", "N=65536 fp32 complex, batch=4096 per GPU (BASELINE configs[1])"),
+    "256k": (1 << 18, 1024, "f32", "N=262144 fp32 complex, batch=1024 per GPU (BASELINE configs[3] shard at 8 GPUs)"),
+    "prime": (1000003, 64, "f64", "N=1000003 (prime) fp64 complex via Bluestein, batch=64 (BASELINE configs[4])"),
+    "1k": (1024, 65536, "f32", "N=1024 fp32 complex, batch=65536 (single-pass LDS kernel)"),
+}
+
+
+def make_input(torch, n, batch, dtype, b0, device):
+    """Closed-form two-tone complex sinusoids: X_b[f_b] = N, X_b[g_b] = N/2, 0 elsewhere."""
+    cdtype = torch.complex64 if dtype == "f32" else torch.complex128
+    out = torch.empty((batch, n), dtype=cdtype, device=device)
+    j = torch.arange(n, dtype=torch.int64, device=device)
+    slab = max(1, min(batch, (1 << 24) // n))
+    for s in range(0, batch, slab):
+        bb = torch.arange(b0 + s, b0 + min(batch, s + slab), dtype=torch.int64, device=device)
+        f = (1 + 7 * bb) % n
+        g = (n // 3 + 13 * bb) % n
+        g = torch.where(g == f, (g + 1) % n, g)
+        pf = (f[:, None] * j[None, :]) % n
+        pg = (g[:, None] * j[None, :]) % n
+        af = pf.to(torch.float64) * (2.0 * 3.14159265358979323846 / n)
+        ag = pg.to(torch.float64) * (2.0 * 3.14159265358979323846 / n)
+        re = torch.cos(af) + 0.5 * torch.cos(ag)
+        im = torch.sin(af) + 0.5 * torch.sin(ag)
+        out[s:s + bb.numel()] = torch.complex(re, im).to(cdtype)
+    return out
+
+
+def cpu_baseline(n, dtype, budget_s=12.0):
+    """Time the reference's own CPU path on this host, on a bounded sample of the same workload.
+
+    kind "reference": radix2_dit_fft (algorithms/core/radix2_dit.c:59-120, what fft_auto runs for every
+    power of two, as split_radix/radix4 are the same loop) from oracle/_ref/libref_fast.so, i.e. the real
+    reference sources built with its shipped optimisation flags (Makefile:7) at a portable ISA level.
+    The reference is fp64-only (complex_t = double complex); all host cores, one transform per thread at a
+    time (task parallelism over the batch index, optimizations/parallel_fft.c:424-427).
+    Falls back to kind "port" (oracle/liboracle_fast.so, the restatement) only if _ref is absent.
+    """
+    import numpy as np
+    import oracle_lib as O
+    kind, fn, blu = None, None, None
+    ref_fast = os.path.join(ROOT, "oracle", "_ref", "libref_fast.so")
+    pow2 = (n & (n - 1)) == 0
+    if os.path.exists(ref_fast):
+        lib = C.CDLL(ref_fast)
+        f = lib.radix2_dit_fft if pow2 else lib.bluestein_fft
+        f.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        f.restype = None
+        kind = "reference"
+
+        def fn(ptr):
+            f(ptr, n, -1)
+    else:
+        import subprocess
+        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "liboracle_fast.so"], check=True)
+        lib = C.CDLL(os.path.join(ROOT, "oracle", "liboracle_fast.so"))
+        lib.oracle_fft_batch.argtypes = [C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_int]
+        kind = "port"
+        algo = 0 if pow2 else 4
+
+        def fn(ptr):
+            lib.oracle_fft_batch(ptr, n, 1, -1, algo)
+    cores = os.cpu_count() or 1
+    threads = max(1, min(cores, 64))
+    x0 = O.gen_two_tone(n, 0, 1)[0]
+    # calibrate on one thread
+    a = x0.copy()
+    t0 = time.perf_counter()
+    fn(a.ctypes.data)
+    t_one = time.perf_counter() - t0
+    reps = max(1, int(budget_s * 0.6 / max(t_one, 1e-6)))
+    reps = min(reps, 200)
+    single = []
+    for _ in range(min(reps, 5)):
+        a = x0.copy()
+        t0 = time.perf_counter()
+        fn(a.ctypes.data)
+        single.append(time.perf_counter() - t0)
+    t_single = min(single)
+    per_thread = max(1, min(reps, int(budget_s * 0.5 / max(t_one, 1e-6))))
+    bufs = [x0.copy() for _ in range(threads)]
+    barrier = threading.Barrier(threads + 1)
+
+    def work(buf):
+        barrier.wait()
+        for _ in range(per_thread):
+            buf[:] = x0
+            fn(buf.ctypes.data)
+        barrier.wait()
+
+    th = [threading.Thread(target=work, args=(b,)) for b in bufs]
+    for t in th:
+        t.start()
+    barrier.wait()
+    t0 = time.perf_counter()
+    barrier.wait()
+    wall = time.perf_counter() - t0
+    for t in th:
+        t.join()
+    total_pts = float(n) * threads * per_thread
+    return {
+        "value": total_pts / wall / 1e9, "unit": "Gpoint/s", "cores": threads, "kind": kind,
+        "sample": "%d transforms of N=%d fp64 (%s, the reference's only precision) per thread on %d threads, "
+                  "two-tone input, forward; 1-thread best: %.4f Gpoint/s (%.1f ms/transform)"
+                  % (per_thread, n, "radix2_dit_fft" if pow2 else "bluestein_fft", threads, n / t_single / 1e9, t_single * 1e3),
+        "single_thread_value": n / t_single / 1e9,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="1m", choices=sorted(WORKLOADS))
+    ap.add_argument("--algo", default="auto")
+    ap.add_argument("--inplace", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-check", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import fftlib
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    n, batch, dtype, desc = WORKLOADS[args.workload]
+    npdtype = np.complex64 if dtype == "f32" else np.complex128
+    esz = 8 if dtype == "f32" else 16
+
+    lib = fftlib.init()
+    plan = fftlib.Plan(n, batch, fftlib.FFT_FORWARD, npdtype, fftlib.ALGO_NAMES[args.algo])
+    stream = torch.cuda.current_stream(device)
+    plan.set_stream(stream.cuda_stream)
+    info = plan.info()
+
+    x = make_input(torch, n, batch, dtype, rank * batch, device)
+    y = x if args.inplace else torch.empty_like(x)
+    if args.inplace:
+        x_keep = None
+    torch.cuda.synchronize()
+
+    def step():
+        plan.execute_ptr(x.data_ptr(), y.data_ptr())
+
+    # ---- correctness of what is being timed: analytic spectrum of every transform (first execute)
+    check = {}
+    if not args.no_check:
+        src = x.clone() if args.inplace else x
+        step()
+        torch.cuda.synchronize()
+        Y = y
+        bb = torch.arange(rank * batch, rank * batch + batch, dtype=torch.int64, device=device)
+        f = (1 + 7 * bb) % n
+        g = (n // 3 + 13 * bb) % n
+        g = torch.where(g == f, (g + 1) % n, g)
+        rows = torch.arange(batch, device=device)
+        pf = Y[rows, f]
+        pg = Y[rows, g]
+        peak_err = max(float((pf - n).abs().max()) / n, float((pg - n / 2).abs().max()) / n)
+        tot = torch.linalg.vector_norm(Y.to(torch.complex128) if dtype == "f32" and batch * n <= (1 << 26) else Y, dim=1)
+        want = float(n) * (1.25 ** 0.5)
+        norm_err = float(((tot - want).abs() / want).max())
+        check = {"peak_rel_err": peak_err, "norm_rel_err": norm_err, "transforms_checked": batch}
+        tol = 1e-4 if dtype == "f32" else 1e-6
+        if not (peak_err < tol and norm_err < tol):
+            raise SystemExit("bench: result check FAILED %r" % (check,))
+        if args.inplace:
+            x.copy_(src)
+            del src
+
+    for _ in range(args.warmup):
+        step()
+        if args.inplace:
+            pass
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- device-side duration of the same K steps, HIP events on the stream the kernels run on
+    ev_ms = plan.timed(x.data_ptr(), y.data_ptr(), args.steps)
+    torch.cuda.synchronize()
+
+    points_per_step = float(n) * batch * world
+    bytes_alg_per_step_gpu = 2.0 * n * batch * esz  # read every input once + write every output once
+    ms_per_step = elapsed / args.steps * 1e3
+    value = points_per_step / (elapsed / args.steps) / 1e9
+    ev_ms_per_step = ev_ms / args.steps
+    achieved = bytes_alg_per_step_gpu / (ev_ms_per_step * 1e-3) / 1e9
+    launches = 0
+    if info.bluestein_m:
+        launches = 3 + 2 * max(1, info.n_passes) * (-(-batch // max(1, info.chunk_batch)) if info.n_passes > 1 else 1)
+    else:
+        launches = info.n_passes * (-(-batch // max(1, info.chunk_batch)) if info.n_passes > 1 else 1)
+
+    result = {
+        "metric": "Gpoint/s + achieved HBM GB/s, batched 1D c2c FFT at 1/2/4/8 MI355X",
+        "value": value, "unit": "Gpoint/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": dtype, "data": "synthetic",
+        "achieved_hbm_gbs": 2.0 * n * batch * world * esz / (elapsed / args.steps) / 1e9,
+        "config": {
+            "workload": desc, "n": n, "batch_per_gpu": batch, "batch_total": batch * world,
+            "direction": "forward", "placement": "in-place" if args.inplace else "out-of-place",
+            "parallelism": "batch index sharded over %d GPU(s), one process per GPU, no collectives" % world,
+            "algo": args.algo, "passes": info.n_passes, "factors": [v for v in info.factors if v],
+            "chunk_batch": info.chunk_batch, "bluestein_m": info.bluestein_m,
+            "device": lib.fft_gpu_get_device_name().decode(),
+        },
+        "roofline": {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "kernel": "tile_fft_kernel x %d launches per step (all passes of the batched FFT)" % launches,
+            "algorithmic_bytes_per_step": bytes_alg_per_step_gpu,
+            "hip_event_ms_per_step": ev_ms_per_step,
+            "note": "achieved = 2*N*batch*sizeof(complex) / HIP-event time of one step on rank 0's stream; "
+                    "traffic (PMC FETCH_SIZE/WRITE_SIZE) is collected by separate rocprofv3 --pmc runs, see profiles/",
+        },
+        "check": check,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            result["cpu_baseline"] = cpu_baseline(n, dtype)
+        except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
+            result["cpu_baseline"] = {"value": None, "unit": "Gpoint/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
+    elif rank == 0:
+        result["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    plan.destroy()
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

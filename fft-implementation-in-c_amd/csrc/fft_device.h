@@ -1,0 +1,107 @@
+// fft_device.h -- device-side vocabulary shared by every kernel of the engine.
+//
+// The kernels are written once.  hipcc compiles them for gfx950 (the product);
+// tests/emu compiles the SAME source with g++ and -DFFT_EMU, where a workgroup
+// is a set of host threads and __syncthreads() a barrier, so that the index
+// algebra (Stockham digit order, four-step strides, LDS layouts) can be checked
+// in the build container, which has no GPU.  The emulation is test
+// infrastructure: nothing in the shipped library is built with FFT_EMU.
+#pragma once
+
+#include <stdint.h>
+
+#if defined(FFT_EMU)
+#include <cstring>
+namespace emu {
+struct dim3_ { unsigned x, y, z; };
+extern thread_local dim3_ threadIdx_;
+extern thread_local dim3_ blockIdx_;
+extern dim3_ blockDim_;
+extern dim3_ gridDim_;
+extern unsigned char* smem_;
+void sync_threads();
+unsigned shfl_xor_u32(unsigned v, int mask);
+}  // namespace emu
+#define FFT_KERNEL
+#define FFT_DEVICE inline
+#define FFT_TID ((int)emu::threadIdx_.x)
+#define FFT_BID ((long long)emu::blockIdx_.x)
+#define FFT_NTHREADS ((int)emu::blockDim_.x)
+#define FFT_NBLOCKS ((long long)emu::gridDim_.x)
+#define FFT_DYN_SMEM(name) unsigned char* name = emu::smem_
+#define FFT_SYNC() emu::sync_threads()
+#define FFT_LAUNCH_BOUNDS(n)
+#define FFT_RESTRICT
+#define FFT_UNROLL
+#else
+#include <hip/hip_runtime.h>
+#define FFT_KERNEL __global__
+#define FFT_DEVICE __device__ __forceinline__
+#define FFT_TID ((int)threadIdx.x)
+#define FFT_BID ((long long)blockIdx.x)
+#define FFT_NTHREADS ((int)blockDim.x)
+#define FFT_NBLOCKS ((long long)gridDim.x)
+#define FFT_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
+#define FFT_SYNC() __syncthreads()
+#define FFT_LAUNCH_BOUNDS(n) __launch_bounds__(n)
+#define FFT_RESTRICT __restrict__
+#define FFT_UNROLL _Pragma("unroll")
+#endif
+
+namespace fftk {
+
+// Interleaved complex value: the device image of complex_t / complex32_t
+// (reference include/fft_common.h:28 -- C99 `double complex` == double[2]).
+template <typename T>
+struct cpx {
+    T re, im;
+};
+
+template <typename T>
+FFT_DEVICE cpx<T> mk(T a, T b) {
+    cpx<T> r;
+    r.re = a;
+    r.im = b;
+    return r;
+}
+template <typename T>
+FFT_DEVICE cpx<T> cadd(cpx<T> a, cpx<T> b) { return mk<T>(a.re + b.re, a.im + b.im); }
+template <typename T>
+FFT_DEVICE cpx<T> csub(cpx<T> a, cpx<T> b) { return mk<T>(a.re - b.re, a.im - b.im); }
+template <typename T>
+FFT_DEVICE cpx<T> cmul(cpx<T> a, cpx<T> b) {
+    return mk<T>(a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re);
+}
+template <typename T>
+FFT_DEVICE cpx<T> cmul_conj(cpx<T> a, cpx<T> b) {  // a * conj(b)
+    return mk<T>(a.re * b.re + a.im * b.im, a.im * b.re - a.re * b.im);
+}
+template <typename T>
+FFT_DEVICE cpx<T> cscale(cpx<T> a, T s) { return mk<T>(a.re * s, a.im * s); }
+template <typename T>
+FFT_DEVICE cpx<T> mul_neg_i(cpx<T> a) { return mk<T>(a.im, -a.re); }  // a * (-i)
+template <typename T>
+FFT_DEVICE cpx<T> mul_pos_i(cpx<T> a) { return mk<T>(-a.im, a.re); }  // a * (+i)
+template <typename T>
+FFT_DEVICE cpx<T> cswap(cpx<T> a) { return mk<T>(a.im, a.re); }
+
+// One 16-byte lane access: 2 adjacent complex32 or 1 complex128.  Every HBM
+// and LDS data access of the tile kernels moves one of these per lane
+// (global_load_dwordx4 / ds_read_b128).
+template <typename T>
+struct alignas(16) vec16 {
+    static constexpr int V = 16 / (int)sizeof(cpx<T>);
+    cpx<T> c[V];
+};
+
+FFT_DEVICE unsigned bitrev32(unsigned v, int log2n) {
+    // reverse the low log2n bits (reference include/fft_common.h:59-77, all log2n)
+    v = ((v >> 1) & 0x55555555u) | ((v & 0x55555555u) << 1);
+    v = ((v >> 2) & 0x33333333u) | ((v & 0x33333333u) << 2);
+    v = ((v >> 4) & 0x0F0F0F0Fu) | ((v & 0x0F0F0F0Fu) << 4);
+    v = ((v >> 8) & 0x00FF00FFu) | ((v & 0x00FF00FFu) << 8);
+    v = (v >> 16) | (v << 16);
+    return log2n > 0 ? (v >> (32 - log2n)) : 0u;
+}
+
+}  // namespace fftk

@@ -1,0 +1,501 @@
+// fft_engine.h -- host-side planner and launcher of the power-of-two engine and
+// of Bluestein on top of it.
+//
+// Templated on a runtime policy RT so that the same planning / launch code is
+// driven by the HIP runtime in the product (fft_hip_backend.hip) and by the
+// thread-based kernel emulation in tests/emu (no GPU in the build container).
+//
+// RT must provide:
+//   void* dmalloc(size_t bytes);  void dfree(void*);
+//   void  h2d(void* dst, const void* src, size_t bytes);          // blocking
+//   template <class K, class... A> void launch(K kernel, long long grid, int block, size_t smem, A... args);
+//   int   max_lds_bytes();
+//
+// Scheme (reference optimizations/parallel_fft.c:213-272 is the
+// CPU statement of the same four-step idea):
+//   n <= one LDS tile        1 pass : rows in, rows out
+//   n = L1*L2                2 passes: A = L2-strided column FFTs of length L1 + twiddle W_n^(k1 n2), written
+//                                      in place-shaped into scratch; B = contiguous row FFTs of length L2,
+//                                      transposed (c-contiguous) store => natural order, no separate transpose
+//   n = L1*L2*L3             3 passes: A on n, then A on the rows of length L2*L3, then B
+// The batch is processed in chunks so that the scratch image (chunk*n elements)
+// can stay resident in the 256 MiB Infinity Cache between the passes.
+#pragma once
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <map>
+#include <vector>
+
+#include "fft_kernels.h"
+
+namespace ffteng {
+
+using fftk::cpx;
+
+enum Algo { ALGO_AUTO = 0, ALGO_RADIX2 = 1, ALGO_RADIX4 = 2, ALGO_SPLIT_RADIX = 3, ALGO_RADIX2_GLOBAL = 4 };
+
+struct PassDesc {
+    int log2L = 0, log2C = 0, E = 16;
+    int loadm = 0, storem = 0, twiddle = 0;
+    int n_ct = 1, n_o = 1;
+    long long n_b_per_transform = 1;  // tiles along "b" contributed by ONE transform of the batch
+    long long in_b = 0, in_o = 0, in_c = 0, in_l = 0;
+    long long out_b = 0, out_o = 0, out_c = 0, out_k = 0;
+    int n_cols = 0;  // valid columns along the tiled dimension; -1: the batch (single-pass row kernel)
+    int log2Ntw = 0;
+    int nthreads = 0;
+    int smem_bytes = 0;
+    int off_tw_stage = 0, off_tw_lo = 0, off_tw_hi = 0;
+    int seg_bytes = 0;  // contiguous bytes per row segment on the c-contiguous side
+};
+
+inline int ilog2(long long v) {
+    int l = 0;
+    while (v > 1) { v >>= 1; l++; }
+    return l;
+}
+
+template <typename T>
+static void make_twiddle_table(std::vector<cpx<T>>& t, long long period, long long count, long long step) {
+    // t[i] = exp(-2 pi i * (i*step) / period), evaluated in long double, rounded once
+    t.resize((size_t)count);
+    const long double two_pi = 6.283185307179586476925286766559005768L;
+    for (long long i = 0; i < count; i++) {
+        long long m = (i * step) % period;
+        // exact symmetry reduction to the first octant keeps cos/sin arguments small
+        long double ang = two_pi * (long double)m / (long double)period;
+        t[(size_t)i].re = (T)cosl(ang);
+        t[(size_t)i].im = (T)(-sinl(ang));
+        if (m == 0) { t[(size_t)i].re = (T)1; t[(size_t)i].im = (T)0; }
+        else if (4 * m == period) { t[(size_t)i].re = (T)0; t[(size_t)i].im = (T)-1; }
+        else if (2 * m == period) { t[(size_t)i].re = (T)-1; t[(size_t)i].im = (T)0; }
+        else if (4 * m == 3 * period) { t[(size_t)i].re = (T)0; t[(size_t)i].im = (T)1; }
+    }
+}
+
+template <typename T, typename RT>
+class Pow2Plan {
+  public:
+    static constexpr int V = 16 / (int)sizeof(cpx<T>);
+    static constexpr int SZ = (int)sizeof(cpx<T>);
+
+    RT* rt = nullptr;
+    int log2n = 0;
+    int algo = ALGO_AUTO;  // resolved (never AUTO after build)
+    int fam = fftk::FAM_SR16;
+    int max_batch = 1;
+    int chunk = 1;  // transforms per launch group
+    std::vector<PassDesc> passes;
+    cpx<T>* scratch = nullptr;
+    size_t scratch_bytes = 0;
+    std::map<int, cpx<T>*> stage_tables;             // log2L -> device W_L
+    std::map<int, std::pair<cpx<T>*, cpx<T>*>> pair_tables;  // log2Ntw -> (lo, hi)
+    cpx<T>* tw_half = nullptr;  // W_n^k, k < n/2 (RADIX2_GLOBAL)
+    bool ok = false;
+
+    ~Pow2Plan() { destroy(); }
+
+    void destroy() {
+        if (!rt) return;
+        for (auto& kv : stage_tables) rt->dfree(kv.second);
+        for (auto& kv : pair_tables) { rt->dfree(kv.second.first); rt->dfree(kv.second.second); }
+        stage_tables.clear();
+        pair_tables.clear();
+        if (tw_half) rt->dfree(tw_half);
+        if (scratch) rt->dfree(scratch);
+        tw_half = nullptr;
+        scratch = nullptr;
+    }
+
+    // ---- LDS footprint of one pass for a candidate (L, C)
+    static int lds_bytes(int log2L, int log2C, int loadm, int storem, int twiddle, int log2Ntw, int* off_s, int* off_lo,
+                         int* off_hi) {
+        const long long L = 1ll << log2L, C = 1ll << log2C;
+        long long data = C * L * SZ;
+        if (loadm == fftk::LOAD_LCONTIG || storem == fftk::STORE_LCONTIG) {
+            long long staged = C * (L * SZ + 16);
+            if (staged > data) data = staged;
+        }
+        long long off = (data + 15) & ~15ll;
+        if (off_s) *off_s = (int)off;
+        off += L * SZ;
+        if (off_lo) *off_lo = (int)off;
+        if (twiddle) {
+            const int log2lo = (log2Ntw + 1) / 2;
+            off += (1ll << log2lo) * SZ;
+            if (off_hi) *off_hi = (int)off;
+            off += (1ll << (log2Ntw - log2lo)) * SZ;
+        } else if (off_hi) {
+            *off_hi = (int)off;
+        }
+        return off > 0x7fffffff ? 0x7fffffff : (int)off;
+    }
+
+    // choose the column count of a tile: first reach a 128-byte row segment, then >= 256 threads
+    static bool choose_tile(PassDesc& p, long long extent_cols, int budget) {
+        const int log2E = ilog2(p.E);
+        int best = -1;
+        for (int lc = ilog2(V); (1ll << lc) <= extent_cols || lc == ilog2(V); lc++) {
+            const long long threads = (1ll << (lc - ilog2(V))) << (p.log2L - log2E);
+            if (threads > 512) break;
+            int b = lds_bytes(p.log2L, lc, p.loadm, p.storem, p.twiddle, p.log2Ntw, nullptr, nullptr, nullptr);
+            if (b > budget) break;
+            best = lc;
+            const bool seg_ok = ((1ll << lc) * SZ) >= 128;
+            if (seg_ok && threads >= 256) break;
+        }
+        if (best < 0) return false;
+        p.log2C = best;
+        p.nthreads = (int)((1ll << (best - ilog2(V))) << (p.log2L - log2E));
+        p.smem_bytes = lds_bytes(p.log2L, best, p.loadm, p.storem, p.twiddle, p.log2Ntw, &p.off_tw_stage, &p.off_tw_lo,
+                                 &p.off_tw_hi);
+        long long seg = (1ll << best) * SZ;
+        p.seg_bytes = (int)(seg > 1 << 20 ? 1 << 20 : seg);
+        return true;
+    }
+
+    static double seg_cost(int seg_bytes) {
+        if (seg_bytes >= 128) return 1.0;
+        if (seg_bytes >= 64) return 1.35;
+        if (seg_bytes >= 32) return 2.2;
+        return 4.0;
+    }
+
+    bool build(RT* runtime, int log2n_, int algo_, int batch) {
+        rt = runtime;
+        log2n = log2n_;
+        max_batch = batch;
+        algo = algo_ == ALGO_AUTO ? ALGO_SPLIT_RADIX : algo_;
+        fam = algo == ALGO_RADIX2 ? fftk::FAM_R2 : algo == ALGO_RADIX4 ? fftk::FAM_R4 : fftk::FAM_SR16;
+        const long long n = 1ll << log2n;
+        if (algo == ALGO_RADIX2_GLOBAL) {
+            if (log2n >= 1) {
+                std::vector<cpx<T>> t;
+                make_twiddle_table<T>(t, n, n / 2, 1);
+                tw_half = (cpx<T>*)rt->dmalloc(t.size() * SZ);
+                if (!tw_half) return false;
+                rt->h2d(tw_half, t.data(), t.size() * SZ);
+            }
+            chunk = batch;
+            ok = true;
+            return true;
+        }
+        if (log2n == 0) { ok = true; chunk = batch; return true; }
+
+        const int budget = rt->max_lds_bytes();
+        std::vector<PassDesc> best;
+        double best_cost = 1e30;
+        // Cost model = relative HBM time: every pass reads and writes the data once (0.5 + 0.5); a
+        // c-contiguous side whose row segments are shorter than 128 B pays seg_cost(); fewer passes win.
+        int force[3] = {0, 0, 0};
+        int n_force = 0;
+        if (const char* e = getenv("FFT_HIP_FORCE_SPLIT")) n_force = sscanf(e, "%d,%d,%d", &force[0], &force[1], &force[2]);
+        if (n_force > 0 && force[0] + force[1] + force[2] != log2n) n_force = 0;
+
+        // ---- candidate: single pass (rows in, rows out)
+        if (n_force <= 1) {
+            PassDesc p;
+            p.log2L = log2n;
+            p.E = n < 16 ? (int)n : 16;
+            p.loadm = fftk::LOAD_LCONTIG;
+            p.storem = fftk::STORE_LCONTIG;
+            p.in_c = n; p.in_l = 1; p.out_c = n; p.out_k = 1;
+            p.n_cols = -1;
+            long long ext = 1;
+            while (ext < batch) ext <<= 1;
+            if (ext < V) ext = V;
+            if (choose_tile(p, ext, budget)) {
+                best.assign(1, p);
+                best_cost = 1.0;
+            }
+        }
+        // ---- candidates: two passes n = L1 * L2
+        for (int l1 = 4; l1 <= log2n - 4; l1++) {
+            const int l2 = log2n - l1;
+            if (n_force >= 1 && !(n_force == 2 && force[0] == l1)) continue;
+            PassDesc a, b;
+            a.log2L = l1; a.loadm = fftk::LOAD_CCONTIG; a.storem = fftk::STORE_CCONTIG; a.twiddle = 1; a.log2Ntw = log2n;
+            a.in_b = n; a.in_c = 1; a.in_l = 1ll << l2; a.out_b = n; a.out_c = 1; a.out_k = 1ll << l2;
+            a.n_cols = 1 << l2;
+            if (!choose_tile(a, 1ll << l2, budget)) continue;
+            a.n_ct = (1 << l2) >> a.log2C;
+            b.log2L = l2; b.loadm = fftk::LOAD_LCONTIG; b.storem = fftk::STORE_CCONTIG;
+            b.in_b = n; b.in_c = 1ll << l2; b.in_l = 1; b.out_b = n; b.out_c = 1; b.out_k = 1ll << l1;
+            b.n_cols = 1 << l1;
+            if (!choose_tile(b, 1ll << l1, budget)) continue;
+            b.n_ct = (1 << l1) >> b.log2C;
+            const double cost = seg_cost(a.seg_bytes) + 0.5 + 0.5 * seg_cost(b.seg_bytes) + 0.01 * abs(l1 - l2);
+            if (cost < best_cost) {
+                best_cost = cost;
+                best.clear();
+                best.push_back(a);
+                best.push_back(b);
+            }
+        }
+        // ---- candidates: three passes n = L1 * L2 * L3
+        if (log2n >= 12) {
+            for (int l1 = 4; l1 <= log2n - 8; l1++)
+                for (int l2 = 4; l2 <= log2n - l1 - 4; l2++) {
+                    const int l3 = log2n - l1 - l2;
+                    if (l1 > 12 || l2 > 12 || l3 > 12) continue;
+                    if (n_force >= 1 && !(n_force == 3 && force[0] == l1 && force[1] == l2)) continue;
+                    const long long M = 1ll << (l2 + l3);
+                    PassDesc a, m, b;
+                    a.log2L = l1; a.loadm = fftk::LOAD_CCONTIG; a.storem = fftk::STORE_CCONTIG; a.twiddle = 1; a.log2Ntw = log2n;
+                    a.in_b = n; a.in_c = 1; a.in_l = M; a.out_b = n; a.out_c = 1; a.out_k = M;
+                    a.n_cols = (int)M;
+                    if (!choose_tile(a, M, budget)) continue;
+                    a.n_ct = (int)(M >> a.log2C);
+                    m.log2L = l2; m.loadm = fftk::LOAD_CCONTIG; m.storem = fftk::STORE_CCONTIG; m.twiddle = 1; m.log2Ntw = l2 + l3;
+                    m.n_b_per_transform = 1ll << l1;
+                    m.in_b = M; m.in_c = 1; m.in_l = 1ll << l3; m.out_b = M; m.out_c = 1; m.out_k = 1ll << l3;
+                    m.n_cols = 1 << l3;
+                    if (!choose_tile(m, 1ll << l3, budget)) continue;
+                    m.n_ct = (1 << l3) >> m.log2C;
+                    b.log2L = l3; b.loadm = fftk::LOAD_LCONTIG; b.storem = fftk::STORE_CCONTIG;
+                    b.n_o = 1 << l2;
+                    b.in_b = n; b.in_o = 1ll << l3; b.in_c = M; b.in_l = 1;
+                    b.out_b = n; b.out_o = 1ll << l1; b.out_c = 1; b.out_k = 1ll << (l1 + l2);
+                    b.n_cols = 1 << l1;
+                    if (!choose_tile(b, 1ll << l1, budget)) continue;
+                    b.n_ct = (1 << l1) >> b.log2C;
+                    const double cost = seg_cost(a.seg_bytes) + seg_cost(m.seg_bytes) + 0.5 + 0.5 * seg_cost(b.seg_bytes) +
+                                        0.01 * (abs(l1 - l2) + abs(l2 - l3));
+                    if (cost < best_cost) {
+                        best_cost = cost;
+                        best.clear();
+                        best.push_back(a);
+                        best.push_back(m);
+                        best.push_back(b);
+                    }
+                }
+        }
+        if (best.empty()) return false;
+        passes = best;
+
+        // ---- tables
+        for (auto& p : passes) {
+            if (!stage_tables.count(p.log2L)) {
+                std::vector<cpx<T>> t;
+                make_twiddle_table<T>(t, 1ll << p.log2L, 1ll << p.log2L, 1);
+                cpx<T>* d = (cpx<T>*)rt->dmalloc(t.size() * SZ);
+                if (!d) return false;
+                rt->h2d(d, t.data(), t.size() * SZ);
+                stage_tables[p.log2L] = d;
+            }
+            if (p.twiddle && !pair_tables.count(p.log2Ntw)) {
+                const int log2lo = (p.log2Ntw + 1) / 2;
+                std::vector<cpx<T>> lo, hi;
+                make_twiddle_table<T>(lo, 1ll << p.log2Ntw, 1ll << log2lo, 1);
+                make_twiddle_table<T>(hi, 1ll << p.log2Ntw, 1ll << (p.log2Ntw - log2lo), 1ll << log2lo);
+                cpx<T>* dlo = (cpx<T>*)rt->dmalloc(lo.size() * SZ);
+                cpx<T>* dhi = (cpx<T>*)rt->dmalloc(hi.size() * SZ);
+                if (!dlo || !dhi) return false;
+                rt->h2d(dlo, lo.data(), lo.size() * SZ);
+                rt->h2d(dhi, hi.data(), hi.size() * SZ);
+                pair_tables[p.log2Ntw] = std::make_pair(dlo, dhi);
+            }
+        }
+
+        // ---- Infinity-Cache blocking of the batch (multi-pass only)
+        chunk = batch;
+        if (passes.size() > 1) {
+            long long target = 64ll << 20;  // bytes of scratch kept hot between passes
+            if (const char* e = getenv("FFT_HIP_CHUNK_MB")) {
+                long long mb = atoll(e);
+                if (mb > 0) target = mb << 20;
+            }
+            long long per = n * SZ;
+            long long c = target / per;
+            if (c < 1) c = 1;
+            if (c > batch) c = batch;
+            chunk = (int)c;
+            scratch_bytes = (size_t)chunk * (size_t)per;
+            scratch = (cpx<T>*)rt->dmalloc(scratch_bytes);
+            if (!scratch) return false;
+        }
+        ok = true;
+        return true;
+    }
+
+    template <int E, int FAM, int LM, int SM, bool TW>
+    void launch_one(const fftk::TileParams<T>& tp, long long grid, const PassDesc& p) {
+        rt->launch(fftk::tile_fft_kernel<T, E, FAM, LM, SM, TW>, grid, p.nthreads, (size_t)p.smem_bytes, tp);
+    }
+
+    template <int FAM>
+    void launch_fam(const fftk::TileParams<T>& tp, long long grid, const PassDesc& p) {
+        using namespace fftk;
+        if (p.loadm == LOAD_CCONTIG) {
+            launch_one<16, FAM, LOAD_CCONTIG, STORE_CCONTIG, true>(tp, grid, p);
+        } else if (p.storem == STORE_CCONTIG) {
+            launch_one<16, FAM, LOAD_LCONTIG, STORE_CCONTIG, false>(tp, grid, p);
+        } else {
+            switch (p.E) {
+                case 2: launch_one<2, FAM_R2, LOAD_LCONTIG, STORE_LCONTIG, false>(tp, grid, p); break;
+                case 4: launch_one<4, (FAM == FAM_SR16 ? FAM_R4 : FAM), LOAD_LCONTIG, STORE_LCONTIG, false>(tp, grid, p); break;
+                case 8: launch_one<8, FAM, LOAD_LCONTIG, STORE_LCONTIG, false>(tp, grid, p); break;
+                default: launch_one<16, FAM, LOAD_LCONTIG, STORE_LCONTIG, false>(tp, grid, p); break;
+            }
+        }
+    }
+
+    void launch_pass(const PassDesc& p, const cpx<T>* in, cpx<T>* out, int nb, bool inverse, T scale) {
+        fftk::TileParams<T> tp;
+        memset(&tp, 0, sizeof(tp));
+        tp.in = in;
+        tp.out = out;
+        tp.tw_stage = stage_tables[p.log2L];
+        if (p.twiddle) {
+            tp.tw_lo = pair_tables[p.log2Ntw].first;
+            tp.tw_hi = pair_tables[p.log2Ntw].second;
+            tp.tw_log2lo = (p.log2Ntw + 1) / 2;
+            tp.tw_lo_len = 1 << tp.tw_log2lo;
+            tp.tw_hi_len = 1 << (p.log2Ntw - tp.tw_log2lo);
+        }
+        tp.log2L = p.log2L;
+        tp.log2C = p.log2C;
+        tp.n_ct = p.n_ct;
+        tp.n_o = p.n_o;
+        tp.in_b = p.in_b; tp.in_o = p.in_o; tp.in_c = p.in_c; tp.in_l = p.in_l;
+        tp.out_b = p.out_b; tp.out_o = p.out_o; tp.out_c = p.out_c; tp.out_k = p.out_k;
+        tp.off_tw_stage = p.off_tw_stage; tp.off_tw_lo = p.off_tw_lo; tp.off_tw_hi = p.off_tw_hi;
+        tp.inverse = inverse ? 1 : 0;
+        tp.scale = scale;
+        long long grid;
+        if (p.n_cols < 0) {  // single-pass row kernel: columns are the transforms of the batch
+            tp.n_cols = nb;
+            tp.n_ct = (int)((nb + (1ll << p.log2C) - 1) >> p.log2C);
+            grid = tp.n_ct;
+        } else {
+            tp.n_cols = p.n_cols;
+            grid = (long long)nb * p.n_b_per_transform * p.n_o * p.n_ct;
+        }
+        switch (fam) {
+            case fftk::FAM_R2: launch_fam<fftk::FAM_R2>(tp, grid, p); break;
+            case fftk::FAM_R4: launch_fam<fftk::FAM_R4>(tp, grid, p); break;
+            default: launch_fam<fftk::FAM_SR16>(tp, grid, p); break;
+        }
+    }
+
+    static long long grid_for(long long total, int block) {
+        long long g = (total + block - 1) / block;
+        if (g > 16384) g = 16384;
+        if (g < 1) g = 1;
+        return g;
+    }
+
+    // Transform `nb` contiguous transforms (nb <= max_batch); in == out allowed.
+    void execute(const cpx<T>* in, cpx<T>* out, int nb, bool inverse, bool scale_inverse = true) {
+        const long long n = 1ll << log2n;
+        const T scale = (inverse && scale_inverse) ? (T)(1.0L / (long double)n) : (T)1;
+        if (log2n == 0) {
+            if (in != out || scale != (T)1)
+                rt->launch(fftk::scale_copy_kernel<T>, grid_for(nb, 256), 256, (size_t)0, in, out, (long long)nb, scale);
+            return;
+        }
+        if (algo == ALGO_RADIX2_GLOBAL) {
+            const long long total = (long long)nb * n;
+            rt->launch(fftk::bitrev_kernel<T>, grid_for(total, 256), 256, (size_t)0, in, out, log2n, total);
+            for (int s = 1; s <= log2n; s++)
+                rt->launch(fftk::radix2_dit_stage_kernel<T>, grid_for(total / 2, 256), 256, (size_t)0, out,
+                           (const cpx<T>*)tw_half, log2n, s, total / 2, inverse ? 1 : 0, s == log2n ? scale : (T)1);
+            return;
+        }
+        if (passes.size() == 1) {
+            launch_pass(passes[0], in, out, nb, inverse, scale);
+            return;
+        }
+        for (int b0 = 0; b0 < nb; b0 += chunk) {
+            const int cb = (nb - b0) < chunk ? (nb - b0) : chunk;
+            const cpx<T>* src = in + (size_t)b0 * (size_t)n;
+            cpx<T>* dst = out + (size_t)b0 * (size_t)n;
+            if (passes.size() == 2) {
+                launch_pass(passes[0], src, scratch, cb, inverse, (T)1);
+                launch_pass(passes[1], scratch, dst, cb, inverse, scale);
+            } else {
+                launch_pass(passes[0], src, scratch, cb, inverse, (T)1);
+                launch_pass(passes[1], scratch, scratch, cb, inverse, (T)1);
+                launch_pass(passes[2], scratch, dst, cb, inverse, scale);
+            }
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------
+// Bluestein plan (reference algorithms/core/bluestein.c:79-155), any n >= 1.
+// The chirp and FFT(b) are computed ONCE at plan time (the reference recomputes
+// both per call); the chirp phase k^2 mod 2n is reduced in integers.
+// ---------------------------------------------------------------------------
+template <typename T, typename RT>
+class BluesteinPlan {
+  public:
+    static constexpr int SZ = (int)sizeof(cpx<T>);
+    RT* rt = nullptr;
+    int n = 0, log2m = 0, dir = -1, max_batch = 1;
+    Pow2Plan<T, RT> core;
+    cpx<T>* chirp = nullptr;  // n entries, reference's chirp[k] = exp(i * (-dir) * pi k^2 / n)
+    cpx<T>* bfft = nullptr;   // m entries
+    cpx<T>* work = nullptr;   // max_batch * m
+    bool ok = false;
+
+    ~BluesteinPlan() {
+        if (!rt) return;
+        if (chirp) rt->dfree(chirp);
+        if (bfft) rt->dfree(bfft);
+        if (work) rt->dfree(work);
+    }
+
+    bool build(RT* runtime, int n_, int dir_, int algo, int batch) {
+        rt = runtime;
+        n = n_;
+        dir = dir_;
+        max_batch = batch;
+        long long m = 1;
+        while (m < 2ll * n - 1) m <<= 1;
+        log2m = ilog2(m);
+        if (!core.build(rt, log2m, algo, batch)) return false;
+        std::vector<cpx<T>> c((size_t)n), b((size_t)m);
+        const long double pi = 3.141592653589793238462643383279502884L;
+        for (long long k = 0; k < n; k++) {
+            const long long p = (k * k) % (2ll * n);
+            const long double ang = pi * (long double)p / (long double)n * (long double)(-dir);
+            c[(size_t)k].re = (T)cosl(ang);
+            c[(size_t)k].im = (T)sinl(ang);
+        }
+        for (long long k = 0; k < m; k++) { b[(size_t)k].re = 0; b[(size_t)k].im = 0; }
+        for (long long k = 0; k < n; k++) {
+            b[(size_t)k] = c[(size_t)k];
+            if (k > 0) b[(size_t)(m - k)] = c[(size_t)k];
+        }
+        chirp = (cpx<T>*)rt->dmalloc((size_t)n * SZ);
+        bfft = (cpx<T>*)rt->dmalloc((size_t)m * SZ);
+        work = (cpx<T>*)rt->dmalloc((size_t)batch * (size_t)m * SZ);
+        if (!chirp || !bfft || !work) return false;
+        rt->h2d(chirp, c.data(), (size_t)n * SZ);
+        rt->h2d(bfft, b.data(), (size_t)m * SZ);
+        core.execute(bfft, bfft, 1, false);
+        ok = true;
+        return true;
+    }
+
+    void execute(const cpx<T>* in, cpx<T>* out, int nb) {
+        const long long m = 1ll << log2m;
+        const long long tot_m = (long long)nb * m, tot_n = (long long)nb * n;
+        rt->launch(fftk::blu_modulate_kernel<T>, Pow2Plan<T, RT>::grid_for(tot_m, 256), 256, (size_t)0, in,
+                   (const cpx<T>*)chirp, work, n, log2m, tot_m);
+        core.execute(work, work, nb, false);
+        rt->launch(fftk::blu_pointwise_kernel<T>, Pow2Plan<T, RT>::grid_for(tot_m, 256), 256, (size_t)0, work,
+                   (const cpx<T>*)bfft, log2m, tot_m);
+        core.execute(work, work, nb, true);  // carries the 1/m
+        const T scale = dir > 0 ? (T)(1.0L / (long double)n) : (T)1;
+        rt->launch(fftk::blu_demodulate_kernel<T>, Pow2Plan<T, RT>::grid_for(tot_n, 256), 256, (size_t)0,
+                   (const cpx<T>*)work, (const cpx<T>*)chirp, out, n, log2m, tot_n, scale);
+    }
+};
+
+}  // namespace ffteng

@@ -1,0 +1,126 @@
+/*
+ * fft_hip.h -- C ABI of the MI355X (gfx950) HIP FFT backend, and the
+ * additive public entry points built on it.
+ *
+ * Part 1 is the drop-in boundary: the 13 backend functions the reference's
+ * dispatcher expects of a backend -- the `extern` block of gpu/fft_gpu.c:32-46
+ * (CUDA flavour; the functions being replaced live in gpu/fft_cuda.cu:53-252).
+ * Plain C types only; opaque handles; no torch / HIP types in signatures
+ * (streams travel as void*).  INTEGRATION.md shows the three-line patch that
+ * binds the reference's own fft_gpu.c to these symbols.
+ *
+ * Part 2 is additive (nothing in the reference has these): fp32, batches with
+ * 64-bit offsets, raw device pointers, streams, multi-device, algorithm
+ * selection, the stand-alone bit-reversal permutation, HIP-event timing.
+ */
+#ifndef FFT_HIP_H
+#define FFT_HIP_H
+
+#include <stdint.h>
+#include "fft_common.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef FFT_GPU_H
+typedef struct fft_gpu_memory* fft_gpu_memory_t;
+typedef struct fft_gpu_plan* fft_gpu_plan_t;
+#endif
+
+/* ------------------------------------------------------------------ part 1
+ * Backend symbol set (replaces fft_gpu_*_cuda, gpu/fft_cuda.cu).          */
+int fft_gpu_init_hip(void);               /* replaces fft_gpu_init_cuda        fft_cuda.cu:53-83   */
+void fft_gpu_cleanup_hip(void);           /* replaces fft_gpu_cleanup_cuda     fft_cuda.cu:86-91   */
+int fft_gpu_available_hip(void);          /* replaces fft_gpu_available_cuda   fft_cuda.cu:94-100  */
+fft_gpu_memory_t fft_gpu_alloc_hip(size_t n_complex);                 /* fft_cuda.cu:103-115 */
+void fft_gpu_free_hip(fft_gpu_memory_t mem);                          /* fft_cuda.cu:118-123 */
+void fft_gpu_copy_h2d_hip(fft_gpu_memory_t dst, const complex_t* src, size_t n_complex); /* :126-129 */
+void fft_gpu_copy_d2h_hip(complex_t* dst, fft_gpu_memory_t src, size_t n_complex);       /* :132-135 */
+fft_gpu_plan_t fft_gpu_plan_1d_hip(int n, int batch, fft_direction dir);                 /* :138-163 */
+/* `dir` is accepted for signature compatibility and IGNORED: the reference's
+ * dispatcher hard-codes FFT_FORWARD there (gpu/fft_gpu.c:252); the plan's own
+ * direction is used. */
+void fft_gpu_execute_hip(fft_gpu_plan_t plan, fft_gpu_memory_t in, fft_gpu_memory_t out, fft_direction dir); /* :166-185 */
+void fft_gpu_destroy_plan_hip(fft_gpu_plan_t plan);                   /* fft_cuda.cu:188-193 */
+const char* fft_gpu_get_device_name_hip(void);                        /* fft_cuda.cu:196-206 */
+void fft_gpu_get_memory_info_hip(size_t* total, size_t* available);   /* fft_cuda.cu:209-211 */
+int fft_gpu_dft_1d_hip(complex_t* in, complex_t* out, int n, fft_direction dir); /* fft_cuda.cu:214-252 */
+
+/* ------------------------------------------------------------------ part 2 */
+typedef enum {
+    FFT_PREC_F64 = 0, /* complex_t   : interleaved double (the reference's only type) */
+    FFT_PREC_F32 = 1  /* complex32_t : interleaved float  (additive)                  */
+} fft_precision_t;
+
+/* Which butterfly family the power-of-two engine uses.  All compute the same
+ * DFT (as radix4_fft / split_radix_fft / radix2_dit_fft do in the reference:
+ * algorithms/core/radix4.c:98-125, split_radix.c:23-55 are radix-2 loops). */
+typedef enum {
+    FFT_GPU_ALGO_AUTO = 0,          /* fastest known schedule for the size               */
+    FFT_GPU_ALGO_RADIX2 = 1,        /* LDS Stockham, radix-2 passes only                 */
+    FFT_GPU_ALGO_RADIX4 = 2,        /* LDS Stockham, radix-4 passes (+ one radix-2)      */
+    FFT_GPU_ALGO_SPLIT_RADIX = 3,   /* LDS Stockham, radix-8/16 passes with split-radix (L-shaped) codelets */
+    FFT_GPU_ALGO_RADIX2_GLOBAL = 4, /* reference-shaped: bit-reversal permutation kernel + log2(n)
+                                       in-place radix-2 DIT stage kernels in HBM (radix2_dit.c:70-112) */
+    FFT_GPU_ALGO_BLUESTEIN = 5      /* chirp-z even when n is a power of two (bluestein.c:79-155);
+                                       every non-power-of-two n uses it whatever algo says */
+} fft_gpu_algo_t;
+
+typedef struct {
+    int n;              /* transform length */
+    int batch;          /* transforms per execute */
+    int direction;      /* -1 / +1 */
+    int precision;      /* fft_precision_t */
+    int algo;           /* fft_gpu_algo_t actually used */
+    int device;         /* HIP device ordinal the plan lives on */
+    int bluestein_m;    /* 0 for power-of-two n, else the padded length */
+    int n_passes;       /* HBM round trips of the power-of-two engine (1, 2 or 3; log2n+1 for RADIX2_GLOBAL) */
+    int factors[4];     /* length of the LDS-resident sub-transform of each pass */
+    int chunk_batch;    /* transforms processed per launch group (Infinity-Cache blocking) */
+    size_t workspace_bytes;
+} fft_gpu_plan_info_t;
+
+/* backend-level additive entry points */
+int fft_gpu_device_count_hip(void);
+int fft_gpu_set_device_hip(int device);
+int fft_gpu_get_device_hip(void);
+fft_gpu_memory_t fft_gpu_alloc_bytes_hip(size_t bytes);
+int fft_gpu_copy_h2d_bytes_hip(fft_gpu_memory_t dst, const void* src, size_t bytes);
+int fft_gpu_copy_d2h_bytes_hip(void* dst, fft_gpu_memory_t src, size_t bytes);
+void* fft_gpu_memory_ptr_hip(fft_gpu_memory_t mem);
+size_t fft_gpu_memory_bytes_hip(fft_gpu_memory_t mem);
+fft_gpu_plan_t fft_gpu_plan_1d_ex_hip(int n, int batch, fft_direction dir, fft_precision_t prec, fft_gpu_algo_t algo);
+int fft_gpu_plan_info_hip(fft_gpu_plan_t plan, fft_gpu_plan_info_t* info);
+int fft_gpu_plan_set_stream_hip(fft_gpu_plan_t plan, void* hip_stream); /* NULL = the plan's own stream */
+int fft_gpu_execute_ptr_hip(fft_gpu_plan_t plan, const void* d_in, void* d_out); /* async on the plan's stream */
+int fft_gpu_plan_sync_hip(fft_gpu_plan_t plan);
+/* `iters` back-to-back executes bracketed by hipEvents recorded on the plan's stream */
+int fft_gpu_execute_timed_hip(fft_gpu_plan_t plan, const void* d_in, void* d_out, int iters, float* elapsed_ms);
+int fft_gpu_dft_1d_batch_hip(const void* in, void* out, int n, int batch, fft_direction dir, fft_precision_t prec);
+/* out[b][bit_reverse(i)] = in[b][i]; in == out allowed (reference: the swap loop radix2_dit.c:70-77) */
+int fft_gpu_bit_reverse_hip(const void* d_in, void* d_out, int n, int batch, fft_precision_t prec, void* hip_stream);
+
+/* public additive API (dispatcher level; same style as fft_gpu.h) */
+int fft_gpu_device_count(void);
+fft_gpu_memory_t fft_gpu_alloc_f32(size_t n_complex32);
+void fft_gpu_copy_h2d_f32(fft_gpu_memory_t dst, const complex32_t* src, size_t n);
+void fft_gpu_copy_d2h_f32(complex32_t* dst, fft_gpu_memory_t src, size_t n);
+void* fft_gpu_memory_ptr(fft_gpu_memory_t mem);
+fft_gpu_plan_t fft_gpu_plan_1d_f32(int n, int batch, fft_direction direction);
+fft_gpu_plan_t fft_gpu_plan_1d_ex(int n, int batch, fft_direction direction, fft_precision_t prec, fft_gpu_algo_t algo);
+int fft_gpu_plan_info(fft_gpu_plan_t plan, fft_gpu_plan_info_t* info);
+int fft_gpu_plan_set_stream(fft_gpu_plan_t plan, void* hip_stream);
+int fft_gpu_execute_async(fft_gpu_plan_t plan, fft_gpu_memory_t in, fft_gpu_memory_t out);
+int fft_gpu_execute_ptr(fft_gpu_plan_t plan, const void* d_in, void* d_out);
+int fft_gpu_plan_sync(fft_gpu_plan_t plan);
+int fft_gpu_execute_timed(fft_gpu_plan_t plan, const void* d_in, void* d_out, int iters, float* elapsed_ms);
+int fft_gpu_dft_1d_f32(complex32_t* in, complex32_t* out, int n, fft_direction direction);
+int fft_gpu_dft_1d_batch_f32(complex32_t* in, complex32_t* out, int n, int batch, fft_direction direction);
+int fft_gpu_bit_reverse(fft_gpu_memory_t in, fft_gpu_memory_t out, int n, int batch, fft_precision_t prec);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* FFT_HIP_H */

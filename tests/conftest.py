@@ -1,0 +1,27 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "fft-implementation-in-c_amd"))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    import numpy as np
+    return np.load(os.path.join(ROOT, "tests", "golden", "reference_vectors.npz"))
+
+
+@pytest.fixture(scope="session")
+def gpu_lib():
+    """The product library, initialised on the GPU.  No fallback: a missing
+    .so or a missing device is a hard failure of every GPU test."""
+    import fftlib
+    lib = fftlib.init()
+    return lib

@@ -1,0 +1,33 @@
+// emu_runtime.h -- a workgroup = host threads, __syncthreads() = a barrier.
+// TEST INFRASTRUCTURE ONLY (see fft_device.h): lets the build container, which
+// has no GPU, execute the unmodified kernel source to check its index algebra.
+#pragma once
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <functional>
+#include <thread>
+#include <vector>
+
+#include "fft_device.h"
+
+namespace emu {
+
+struct Runtime {
+    void* dmalloc(size_t bytes) { return malloc(bytes ? bytes : 16); }
+    void dfree(void* p) { free(p); }
+    void h2d(void* dst, const void* src, size_t bytes) { memcpy(dst, src, bytes); }
+    int lds_budget = 160 * 1024;
+    int max_lds_bytes() { return lds_budget; }
+    long long launches = 0;
+
+    template <class K, class... A>
+    void launch(K kernel, long long grid, int block, size_t smem, A... args) {
+        launches++;
+        run_grid(grid, block, smem, [&]() { kernel(args...); });
+    }
+    static void run_grid(long long grid, int block, size_t smem, const std::function<void()>& body);
+};
+
+}  // namespace emu

@@ -1,0 +1,52 @@
+"""ctypes loader for the CPU emulation of the HIP kernels (tests/emu).  Test infra only."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMU_DIR = os.path.join(ROOT, "tests", "emu")
+CSRC = os.path.join(ROOT, "fft-implementation-in-c_amd", "csrc")
+_lib = None
+
+
+def _needs_build(so):
+    if not os.path.exists(so):
+        return True
+    t = os.path.getmtime(so)
+    srcs = [os.path.join(EMU_DIR, f) for f in os.listdir(EMU_DIR) if f.endswith((".cpp", ".h"))]
+    srcs += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    return any(os.path.getmtime(s) > t for s in srcs)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        so = os.path.join(EMU_DIR, "libfft_emu.so")
+        if _needs_build(so):
+            subprocess.run(["g++", "-O1", "-std=c++17", "-DFFT_EMU", "-fPIC", "-shared", "-pthread", "-I" + CSRC,
+                            os.path.join(EMU_DIR, "emu_fft.cpp"), "-o", so], check=True)
+        _lib = C.CDLL(so)
+        _lib.emu_fft.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                 C.POINTER(C.c_int)]
+        _lib.emu_fft.restype = C.c_int
+        _lib.emu_bitrev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+    return _lib
+
+
+def emu_fft(x, direction=-1, algo=0, lds_budget=0, inplace=False):
+    """x: [batch, n] complex64/complex128.  Returns (result, info)."""
+    x = np.ascontiguousarray(x)
+    prec = 1 if x.dtype == np.complex64 else 0
+    batch, n = x.shape
+    info = (C.c_int * 8)()
+    if inplace:
+        out = x.copy()
+        rc = lib().emu_fft(out.ctypes.data, out.ctypes.data, n, batch, direction, prec, algo, lds_budget, info)
+    else:
+        out = np.full_like(x, np.nan)
+        rc = lib().emu_fft(x.ctypes.data, out.ctypes.data, n, batch, direction, prec, algo, lds_budget, info)
+    if rc != 0:
+        raise RuntimeError("emu_fft failed")
+    return out, list(info)

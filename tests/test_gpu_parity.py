@@ -1,0 +1,295 @@
+"""GPU parity tests: the HIP engine, called through the C ABI, against the CPU
+oracle (oracle/oracle_fft.c = restatement of the reference's radix-2 path,
+pinned bit-exact to the real reference in tests/test_oracle_vs_ref.py) and
+against the golden vectors generated from the real reference.
+
+Tolerances (BASELINE.json north_star): rel-L2 <= 1e-6 for fp64, <= 1e-4 for fp32.
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+TOL = {np.dtype(np.complex128): 1e-6, np.dtype(np.complex64): 1e-4}
+# what the engine actually achieves; a regression guard much tighter than the contractual gate
+TIGHT = {np.dtype(np.complex128): 5e-13, np.dtype(np.complex64): 2e-6}
+
+
+def rel(a, b):
+    a = np.asarray(a, dtype=np.complex128)
+    b = np.asarray(b, dtype=np.complex128)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+def lcg(n, batch, dtype, seed=0):
+    return O.gen_lcg(n, seed, batch).astype(dtype)
+
+
+ALGOS = ["auto", "radix2", "radix4", "split_radix", "radix2_global"]
+
+
+@pytest.mark.parametrize("dtype", [np.complex128, np.complex64])
+@pytest.mark.parametrize("algo", ALGOS)
+@pytest.mark.parametrize("n", [2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096])
+def test_small_pow2_vs_oracle(gpu_lib, dtype, algo, n):
+    import fftlib
+    x = lcg(n, 5, dtype, seed=n)
+    for d in (-1, 1):
+        y = fftlib.fft(x, d, fftlib.ALGO_NAMES[algo])
+        # oracle = reference radix-2 DIT restatement; for n in {4, 8, 16} the reference itself is wrong
+        # (bit_reverse bug) so the exact-DFT oracle is used there
+        ref = O.oracle_fft(x.astype(np.complex128), d, "dit" if n >= 32 or n == 2 else "naive")
+        r = rel(y, ref)
+        assert r <= TOL[np.dtype(dtype)], (n, d, algo, r)
+        assert r <= TIGHT[np.dtype(dtype)], (n, d, algo, r)
+
+
+@pytest.mark.parametrize("dtype", [np.complex128, np.complex64])
+@pytest.mark.parametrize("log2n", [13, 14, 15, 16, 17, 18, 20])
+def test_multipass_vs_oracle(gpu_lib, dtype, log2n):
+    import fftlib
+    n = 1 << log2n
+    batch = 3
+    x = lcg(n, batch, dtype, seed=log2n)
+    for d, inplace in ((-1, True), (1, False)):
+        y = fftlib.fft(x, d, inplace=inplace)
+        ref = O.oracle_fft(x.astype(np.complex128), d, "dit")
+        r = rel(y, ref)
+        assert r <= TOL[np.dtype(dtype)], (n, d, r)
+        assert r <= 10 * TIGHT[np.dtype(dtype)], (n, d, r)
+
+
+@pytest.mark.parametrize("algo", ["radix2", "radix4", "radix2_global"])
+def test_multipass_other_families(gpu_lib, algo):
+    import fftlib
+    n = 1 << 16
+    x = lcg(n, 2, np.complex64, seed=3)
+    y = fftlib.fft(x, -1, fftlib.ALGO_NAMES[algo])
+    ref = O.oracle_fft(x.astype(np.complex128), -1, "dit")
+    assert rel(y, ref) <= 2e-6
+
+
+def test_golden_n1024_all_reference_algorithms(gpu_lib, golden):
+    """BASELINE config 1: N=1024 fp64 against the real reference's own outputs."""
+    import fftlib
+    x = golden["n1024_in"]
+    for ref_algo in ("dit", "dif", "radix4", "split_radix"):
+        for d, tag in ((-1, "fwd"), (1, "inv")):
+            want = golden["n1024_%s_%s" % (ref_algo, tag)]
+            for algo in ALGOS:
+                y = fftlib.fft(x, d, fftlib.ALGO_NAMES[algo])
+                assert rel(y, want) <= 1e-12, (ref_algo, tag, algo)
+
+
+def test_golden_small_sizes(gpu_lib, golden):
+    import fftlib
+    for n in (32, 64, 128, 256, 512):
+        x = golden["n%d_in" % n]
+        assert rel(fftlib.fft(x, -1), golden["n%d_dit_fwd" % n]) <= 1e-13
+        assert rel(fftlib.fft(x, 1), golden["n%d_dit_inv" % n]) <= 1e-13
+
+
+def test_known_answer_n8(gpu_lib, golden):
+    """The only known-answer vector in the reference tree (fft/fft.c:75)."""
+    import fftlib
+    y = fftlib.fft(golden["n8_known_in"], -1)
+    assert np.max(np.abs(y - golden["n8_known_out_3dp"])) < 1e-3
+
+
+@pytest.mark.parametrize("n", [65536, 1 << 18, 1 << 20])
+def test_golden_large_sampled_bins(gpu_lib, golden, n):
+    """Reference outputs at 256 sampled bins + norm, inputs regenerated from the closed forms."""
+    import fftlib
+    bins = golden["n%d_bins" % n]
+    for name, gen in (("tone", lambda: O.gen_two_tone(n, 3, 1)), ("lcg", lambda: O.gen_lcg(n, 3, 1))):
+        x = gen()
+        assert np.array_equal(x[0, :16], golden["n%d_%s_in_head" % (n, name)])
+        for dtype in (np.complex128, np.complex64):
+            y = fftlib.fft(x.astype(dtype), -1)[0]
+            want = golden["n%d_%s_fwd_bins" % (n, name)]
+            scale = golden["n%d_%s_fwd_norm" % (n, name)] / np.sqrt(n)
+            err = np.max(np.abs(y[bins] - want)) / scale
+            assert err <= (1e-9 if dtype == np.complex128 else 3e-5), (n, name, dtype, err)
+            assert abs(np.linalg.norm(y.astype(np.complex128)) / golden["n%d_%s_fwd_norm" % (n, name)] - 1) < TOL[np.dtype(dtype)]
+            yi = fftlib.fft(x.astype(dtype), 1)[0]
+            wanti = golden["n%d_%s_inv_bins" % (n, name)]
+            erri = np.max(np.abs(yi[bins] - wanti)) / (scale / n)
+            assert erri <= (1e-9 if dtype == np.complex128 else 3e-5), (n, name, dtype, erri)
+
+
+@pytest.mark.parametrize("n", [31, 97, 1009])
+def test_bluestein_golden(gpu_lib, golden, n):
+    import fftlib
+    x = golden["blu%d_in" % n]
+    assert rel(fftlib.fft(x, -1), golden["blu%d_fwd" % n]) <= 1e-12
+    assert rel(fftlib.fft(x, 1), golden["blu%d_inv" % n]) <= 1e-12
+    assert rel(fftlib.fft(x.astype(np.complex64), -1), golden["blu%d_fwd" % n]) <= 1e-4
+
+
+@pytest.mark.parametrize("n", [3, 5, 6, 12, 15, 20, 24, 30, 100, 1000, 4097, 65537])
+def test_bluestein_any_n_vs_numpy(gpu_lib, n):
+    """Composite sizes of the reference's test sweep (tests/test_all.c:415) and some primes."""
+    import fftlib
+    x = lcg(n, 3, np.complex128, seed=n)
+    assert rel(fftlib.fft(x, -1), np.fft.fft(x, axis=-1)) <= 1e-12
+    assert rel(fftlib.fft(x, 1), np.fft.ifft(x, axis=-1)) <= 1e-12
+
+
+def test_bluestein_baseline_prime(gpu_lib, golden):
+    """BASELINE config 5 shape: N=1000003 fp64 (batch reduced to 2 for the parity check)."""
+    import fftlib
+    n = 1000003
+    x = O.gen_lcg(n, 5, 2)
+    assert np.array_equal(x[0, :16], golden["blu1000003_in_head"])
+    y = fftlib.fft(x, -1)
+    bins = golden["blu1000003_bins"]
+    scale = golden["blu1000003_fwd_norm"] / np.sqrt(n)
+    assert np.max(np.abs(y[0][bins] - golden["blu1000003_fwd_bins"])) / scale <= 1e-6
+    assert rel(y, np.fft.fft(x, axis=-1)) <= 1e-6
+    back = fftlib.fft(y, 1)
+    assert rel(back, x) <= 1e-6
+
+
+def test_bit_reversal_kernel_index_exact(gpu_lib, golden):
+    """BASELINE config 1's 'bit-exact index check': the permutation kernel against the
+    reference's bit_reverse() table for log2n = 10 (and every log2n the reference gets right)."""
+    import fftlib
+    for log2n in range(5, 13):
+        n = 1 << log2n
+        table = golden["bitrev_ref_log2n_%d" % log2n]
+        assert np.array_equal(table, O.bit_reverse_table(log2n))
+        x = (np.arange(2 * n, dtype=np.float64).reshape(2, n) + 0j)
+        a = fftlib.DeviceBuffer(x.nbytes)
+        b = fftlib.DeviceBuffer(x.nbytes)
+        a.upload(x)
+        assert gpu_lib.fft_gpu_bit_reverse(a.handle, b.handle, n, 2, fftlib.PREC_F64) == 0
+        y = b.download(x.shape, x.dtype)
+        want = np.empty_like(x)
+        want[:, table] = x
+        assert np.array_equal(y, want)
+        assert gpu_lib.fft_gpu_bit_reverse(a.handle, a.handle, n, 2, fftlib.PREC_F64) == 0  # in place
+        assert np.array_equal(a.download(x.shape, x.dtype), want)
+        a.free()
+        b.free()
+
+
+def test_c_api_fft_auto_and_plan(gpu_lib):
+    """fft_auto / fft_plan_dft_1d / fft_execute / fft_execute_dft through the C ABI (config 1 plumbing)."""
+    import fftlib
+    n = 1024
+    x = O.gen_two_tone(n, 0, 1)[0]
+    out = np.zeros_like(x)
+    assert gpu_lib.fft_auto(x.ctypes.data, out.ctypes.data, n, -1) == 0
+    ref = O.oracle_fft(x, -1, "dit")
+    assert rel(out, ref) <= 1e-12
+    f, g = O.two_tone_bins(n, 0)
+    assert abs(out[f] - n) < 1e-9 and abs(out[g] - n / 2) < 1e-9
+    plan = gpu_lib.fft_plan_dft_1d(n, x.ctypes.data, out.ctypes.data, +1, fftlib.FFT_PREFER_GPU)
+    assert plan
+    gpu_lib.fft_execute(plan)
+    assert rel(out, O.oracle_fft(x, 1, "dit")) <= 1e-12
+    x2 = O.gen_lcg(n, 9, 1)[0]
+    y2 = x2.copy()
+    gpu_lib.fft_execute_dft(plan, y2.ctypes.data, y2.ctypes.data)  # in place with a plan made out of place
+    assert rel(y2, O.oracle_fft(x2, 1, "dit")) <= 1e-12
+    gpu_lib.fft_destroy_plan(plan)
+    assert gpu_lib.fft_plan_dft_1d(0, x.ctypes.data, out.ctypes.data, -1, 0) is None
+    assert gpu_lib.fft_plan_dft_1d(n, None, out.ctypes.data, -1, 0) is None
+    assert gpu_lib.fft_auto(x.ctypes.data, out.ctypes.data, -5, -1) == -1
+    z = x.copy()
+    assert gpu_lib.fft_gpu_dft_1d(z.ctypes.data, z.ctypes.data, n, -1) == 0
+    assert rel(z, ref) <= 1e-12
+    xb = O.gen_lcg(256, 1, 7)
+    yb = np.zeros_like(xb)
+    assert gpu_lib.fft_gpu_dft_1d_batch(xb.ctypes.data, yb.ctypes.data, 256, 7, -1) == 0
+    assert rel(yb, O.oracle_fft(xb, -1, "dit")) <= 1e-12
+    for name in ("radix2_dit_fft_gpu", "radix2_fft_gpu", "radix4_fft_gpu", "split_radix_fft_gpu", "bluestein_fft_gpu"):
+        w = x.copy()
+        assert getattr(gpu_lib, name)(w.ctypes.data, n, -1) == 0
+        assert rel(w, ref) <= 1e-12, name
+    w = x[:100].copy()
+    assert gpu_lib.radix4_fft_gpu(w.ctypes.data, 100, -1) == -1  # not a power of two: error, no exit()
+    assert gpu_lib.fft_gpu_get_device_name() != b"No GPU"
+    import ctypes as C
+    tot, av = C.c_size_t(), C.c_size_t()
+    gpu_lib.fft_gpu_get_memory_info(C.byref(tot), C.byref(av))
+    assert tot.value > (100 << 30) and 0 < av.value <= tot.value
+    assert gpu_lib.fft_gpu_plan_2d(4, 4, -1) is None and gpu_lib.fft_gpu_dft_2d(None, None, 4, 4, -1) == -1
+
+
+def test_reference_property_tests(gpu_lib):
+    """Properties 1-6 of the reference's tests/test_all.c:64-351 at n >= 32, its tolerances."""
+    import fftlib
+    rng = np.random.default_rng(7)
+    for n in (32, 64, 128, 256, 512, 1024):
+        tol = 1e-10
+        imp = np.zeros(n, dtype=np.complex128); imp[0] = 1
+        assert np.max(np.abs(np.abs(fftlib.fft(imp, -1)) - 1)) < tol                      # 1 impulse
+        dc = np.ones(n, dtype=np.complex128)
+        X = fftlib.fft(dc, -1)
+        assert abs(X[0] - n) < tol * n and np.max(np.abs(X[1:])) < tol * n                # 2 DC
+        a = rng.random(n) - 0.5 + 1j * (rng.random(n) - 0.5)
+        b = rng.random(n) - 0.5 + 1j * (rng.random(n) - 0.5)
+        lhs = fftlib.fft(2 * a + 3 * b, -1)
+        assert np.max(np.abs(lhs - (2 * fftlib.fft(a, -1) + 3 * fftlib.fft(b, -1)))) < tol * n   # 3 linearity
+        A = fftlib.fft(a, -1)
+        assert abs(np.sum(np.abs(a) ** 2) - np.sum(np.abs(A) ** 2) / n) < tol * n         # 4 Parseval
+        i = np.arange(n)
+        s = (np.sin(2 * np.pi * 3 * i / n) + 0.5 * np.cos(2 * np.pi * 7 * i / n)).astype(np.complex128)
+        assert np.max(np.abs(fftlib.fft(fftlib.fft(s, -1), 1) - s)) < tol                 # 5 round trip
+        f = 5
+        c = np.cos(2 * np.pi * f * i / n).astype(np.complex128)
+        C_ = np.abs(fftlib.fft(c, -1))
+        assert abs(C_[f] - n / 2) < tol * n and abs(C_[n - f] - n / 2) < tol * n          # 6 known transform
+        mask = np.ones(n, bool); mask[[f, n - f]] = False
+        assert np.max(C_[mask]) < tol * n
+
+
+def test_full_size_analytic_two_tone_config2(gpu_lib):
+    """BASELINE config 2 at FULL size (N=65536 fp32, batch=4096): every transform checked against the
+    analytic spectrum X[f_b] = N, X[g_b] = N/2, 0 elsewhere (size-independent property; test_all.c:290-351)."""
+    import fftlib
+    n, batch = 65536, 4096
+    step = 256
+    plan = fftlib.Plan(n, step, -1, np.complex64)
+    buf = fftlib.DeviceBuffer(n * step * 8)
+    for b0 in range(0, batch, step):
+        x = O.gen_two_tone(n, b0, step, np.complex64)
+        buf.upload(x)
+        plan.execute(buf, buf)
+        y = buf.download((step, n), np.complex64)
+        for i in range(0, step, 37):
+            f, g = O.two_tone_bins(n, b0 + i)
+            yy = y[i].astype(np.complex128)
+            assert abs(yy[f] - n) / n < 1e-4 and abs(yy[g] - n / 2) / n < 1e-4
+            yy[f] = 0
+            yy[g] = 0
+            assert np.linalg.norm(yy) / (n * np.sqrt(1.25)) < 1e-4
+    plan.destroy()
+    buf.free()
+
+
+def test_roundtrip_full_size_config3(gpu_lib):
+    """BASELINE config 3 at FULL size (N=2^20 fp32, batch=512): forward then inverse on device returns the
+    input (idempotence-style property), plus oracle parity on the first and last transform."""
+    import fftlib
+    n, batch = 1 << 20, 512
+    fwd = fftlib.Plan(n, batch, -1, np.complex64)
+    inv = fftlib.Plan(n, batch, 1, np.complex64)
+    buf = fftlib.DeviceBuffer(n * batch * 8)
+    x = O.gen_two_tone(n, 0, batch, np.complex64)
+    buf.upload(x)
+    fwd.execute(buf, buf)
+    y = buf.download((batch, n), np.complex64)
+    for b in (0, batch - 1):
+        ref = O.oracle_fft(x[b].astype(np.complex128), -1, "dit")
+        assert rel(y[b], ref) <= 1e-4
+        f, g = O.two_tone_bins(n, b)
+        assert abs(y[b][f] - n) / n < 1e-4 and abs(y[b][g] - n / 2) / n < 1e-4
+    inv.execute(buf, buf)
+    z = buf.download((batch, n), np.complex64)
+    assert rel(z, x) <= 1e-4
+    assert rel(z, x) <= 5e-6
+    fwd.destroy(); inv.destroy(); buf.free()
