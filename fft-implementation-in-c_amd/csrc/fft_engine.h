@@ -366,6 +366,8 @@ class Pow2Plan {
         tp.off_tw_stage = p.off_tw_stage; tp.off_tw_lo = p.off_tw_lo; tp.off_tw_hi = p.off_tw_hi;
         tp.inverse = inverse ? 1 : 0;
         tp.scale = scale;
+        static const int ablate = getenv("FFT_HIP_ABLATE") ? atoi(getenv("FFT_HIP_ABLATE")) : 0;  // profiling only
+        tp.ablate = ablate;
         long long grid;
         if (p.n_cols < 0) {  // single-pass row kernel: columns are the transforms of the batch
             tp.n_cols = nb;

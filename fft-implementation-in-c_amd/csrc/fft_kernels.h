@@ -48,6 +48,7 @@ struct TileParams {
     int tw_lo_len, tw_hi_len;
     int off_tw_stage, off_tw_lo, off_tw_hi;  // byte offsets of the LDS copies of the tables
     int inverse;                             // 1: inverse transform via the re<->im swap identity
+    int ablate;                              // profiling only (FFT_HIP_ABLATE): 1 skip inter-pass twiddle, 2 skip stages, 4 skip stage twiddles
     T scale;                                 // applied at the store (1/N folded into the last pass)
 };
 
@@ -244,7 +245,7 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS(512) tile_fft_kernel(TileParams<T> p) {
     }
 
     // ---- stages
-    {
+    if (!(p.ablate & 2)) {
         int log2Lprev = log2L, log2P = 0;
         const int n_full = log2L / log2RM;
         const int rem = log2L - n_full * log2RM;
@@ -263,7 +264,7 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS(512) tile_fft_kernel(TileParams<T> p) {
     }
 
     // ---- inter-pass twiddle W_Ntw^(K * column), scale, inverse swap
-    if (TWIDDLE) {
+    if (TWIDDLE && !(p.ablate & 1)) {
         const unsigned lo_mask = (1u << p.tw_log2lo) - 1u;
         FFT_UNROLL
         for (int e = 0; e < E; e++) {
