@@ -30,7 +30,10 @@ unsigned shfl_xor_u32(unsigned v, int mask);
 #define FFT_NBLOCKS ((long long)emu::gridDim_.x)
 #define FFT_DYN_SMEM(name) unsigned char* name = emu::smem_
 #define FFT_SYNC() emu::sync_threads()
+#define FFT_SYNC_LDS() emu::sync_threads()
+#define FFT_WAIT_LOADED(v) (void)(v)
 #define FFT_LAUNCH_BOUNDS(n)
+#define FFT_LAUNCH_BOUNDS2(n, w)
 #define FFT_RESTRICT
 #define FFT_UNROLL
 #else
@@ -43,7 +46,16 @@ unsigned shfl_xor_u32(unsigned v, int mask);
 #define FFT_NBLOCKS ((long long)gridDim.x)
 #define FFT_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
 #define FFT_SYNC() __syncthreads()
+// Workgroup barrier that orders LDS traffic only: waits for this wave's LDS operations (lgkmcnt(0)) and
+// joins the barrier WITHOUT draining outstanding global loads (vmcnt untouched), so a prefetch of the next
+// tile issued before the barrier stays in flight across it (__syncthreads() would add s_waitcnt vmcnt(0)).
+#define FFT_SYNC_LDS() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+// A fake use of a loaded register: makes the compiler place the s_waitcnt vmcnt for that load HERE.  vmcnt is
+// an in-order counter shared by loads and stores, so waiting for the prefetched tile BEFORE this tile's
+// stores are issued keeps the store latency out of the next iteration's critical path.
+#define FFT_WAIT_LOADED(v) asm volatile("" ::"v"(v))
 #define FFT_LAUNCH_BOUNDS(n) __launch_bounds__(n)
+#define FFT_LAUNCH_BOUNDS2(n, w) __launch_bounds__(n, w)
 #define FFT_RESTRICT __restrict__
 #define FFT_UNROLL _Pragma("unroll")
 #endif
@@ -53,7 +65,7 @@ namespace fftk {
 // Interleaved complex value: the device image of complex_t / complex32_t
 // (reference include/fft_common.h:28 -- C99 `double complex` == double[2]).
 template <typename T>
-struct cpx {
+struct alignas(2 * sizeof(T)) cpx {  // 8 / 16-byte aligned: one ds_read_b64 / b128, one global_load_dwordx2 / x4
     T re, im;
 };
 

@@ -9,7 +9,7 @@
 //   void* dmalloc(size_t bytes);  void dfree(void*);
 //   void  h2d(void* dst, const void* src, size_t bytes);          // blocking
 //   template <class K, class... A> void launch(K kernel, long long grid, int block, size_t smem, A... args);
-//   int   max_lds_bytes();
+//   int   max_lds_bytes();   int num_cus();
 //
 // Scheme (reference optimizations/parallel_fft.c:213-272 is the
 // CPU statement of the same four-step idea):
@@ -27,7 +27,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include <map>
+#include <algorithm>
 #include <vector>
 
 #include "fft_kernels.h"
@@ -40,6 +40,10 @@ enum Algo { ALGO_AUTO = 0, ALGO_RADIX2 = 1, ALGO_RADIX4 = 2, ALGO_SPLIT_RADIX = 
 
 struct PassDesc {
     int log2L = 0, log2C = 0, E = 16;
+    int log2H = 0;  // column groups per tile (kernel template H = 1 << log2H)
+    int tw_levels = 2;  // inter-pass twiddle: 2- or 3-level table product
+    int sa_bits = 0, t0_bits = 0, t1_bits = 0, t2_bits = 0;
+    int o_sb = 0, o_t0 = 0, o_t1 = 0, o_t2 = 0, tables_elems = 0, off_tables = 0;
     int loadm = 0, storem = 0, twiddle = 0;
     int n_ct = 1, n_o = 1;
     long long n_b_per_transform = 1;  // tiles along "b" contributed by ONE transform of the batch
@@ -49,9 +53,17 @@ struct PassDesc {
     int log2Ntw = 0;
     int nthreads = 0;
     int smem_bytes = 0;
-    int off_tw_stage = 0, off_tw_lo = 0, off_tw_hi = 0;
     int seg_bytes = 0;  // contiguous bytes per row segment on the c-contiguous side
 };
+
+inline int tile_E(long long L) {
+    // elements per thread of a tile kernel: 8 by default (32 data VGPRs + 32 prefetch VGPRs, no spills);
+    // FFT_HIP_E=16 selects the radix-16 variant (fewer LDS exchanges, prefetch only late in the tile)
+    static const int pref = getenv("FFT_HIP_E") ? atoi(getenv("FFT_HIP_E")) : 8;
+    int e = (pref == 16) ? 16 : 8;
+    while (e > L) e >>= 1;
+    return e;
+}
 
 inline int ilog2(long long v) {
     int l = 0;
@@ -92,8 +104,7 @@ class Pow2Plan {
     std::vector<PassDesc> passes;
     cpx<T>* scratch = nullptr;
     size_t scratch_bytes = 0;
-    std::map<int, cpx<T>*> stage_tables;             // log2L -> device W_L
-    std::map<int, std::pair<cpx<T>*, cpx<T>*>> pair_tables;  // log2Ntw -> (lo, hi)
+    std::vector<cpx<T>*> pass_tables;  // one device blob per pass: [sa | sb | t0 | t1 | t2]
     cpx<T>* tw_half = nullptr;  // W_n^k, k < n/2 (RADIX2_GLOBAL)
     bool ok = false;
 
@@ -101,59 +112,81 @@ class Pow2Plan {
 
     void destroy() {
         if (!rt) return;
-        for (auto& kv : stage_tables) rt->dfree(kv.second);
-        for (auto& kv : pair_tables) { rt->dfree(kv.second.first); rt->dfree(kv.second.second); }
-        stage_tables.clear();
-        pair_tables.clear();
+        for (auto* t : pass_tables) rt->dfree(t);
+        pass_tables.clear();
         if (tw_half) rt->dfree(tw_half);
         if (scratch) rt->dfree(scratch);
         tw_half = nullptr;
         scratch = nullptr;
     }
 
-    // ---- LDS footprint of one pass for a candidate (L, C)
-    static int lds_bytes(int log2L, int log2C, int loadm, int storem, int twiddle, int log2Ntw, int* off_s, int* off_lo,
-                         int* off_hi) {
-        const long long L = 1ll << log2L, C = 1ll << log2C;
-        long long data = C * L * SZ;
-        if (loadm == fftk::LOAD_LCONTIG || storem == fftk::STORE_LCONTIG) {
-            long long staged = C * (L * SZ + 16);
-            if (staged > data) data = staged;
+    // ---- twiddle-table layout of a pass: fills the bit splits and element offsets, returns the element count
+    static int layout_tables(PassDesc& p) {
+        const long long L = 1ll << p.log2L;
+        p.sa_bits = (L * SZ > 8192) ? (p.log2L + 1) / 2 : p.log2L;  // two-level stage table above 8 KiB
+        int n = 1 << p.sa_bits;
+        p.o_sb = n;
+        n += 1 << (p.log2L - p.sa_bits);
+        p.o_t0 = p.o_t1 = p.o_t2 = n;
+        p.t0_bits = p.t1_bits = p.t2_bits = 0;
+        if (p.twiddle) {
+            if (p.tw_levels == 2) {  // W^m = t0[lo] * t1[hi]: one complex multiply per element
+                p.t0_bits = (p.log2Ntw + 1) / 2;
+                p.t1_bits = p.log2Ntw - p.t0_bits;
+                p.t2_bits = 0;
+            } else {                 // three short tables when the two-level pair does not fit in LDS
+                p.t0_bits = (p.log2Ntw + 2) / 3;
+                p.t1_bits = (p.log2Ntw - p.t0_bits + 1) / 2;
+                p.t2_bits = p.log2Ntw - p.t0_bits - p.t1_bits;
+            }
+            p.o_t0 = n; n += 1 << p.t0_bits;
+            p.o_t1 = n; n += 1 << p.t1_bits;
+            p.o_t2 = n; n += 1 << p.t2_bits;
         }
+        n = (n * SZ + 15) / 16 * 16 / SZ;
+        p.tables_elems = n;
+        return n;
+    }
+
+    // ---- LDS footprint of one pass for a candidate group width CG = 2^log2CG
+    static int lds_bytes(PassDesc& p, int log2CG) {
+        const long long L = 1ll << p.log2L, CG = 1ll << log2CG;
+        long long data = CG * L * SZ;
+        if (p.loadm == fftk::LOAD_LCONTIG || p.storem == fftk::STORE_LCONTIG) data = CG * (L * SZ + 16);
         long long off = (data + 15) & ~15ll;
-        if (off_s) *off_s = (int)off;
-        off += L * SZ;
-        if (off_lo) *off_lo = (int)off;
-        if (twiddle) {
-            const int log2lo = (log2Ntw + 1) / 2;
-            off += (1ll << log2lo) * SZ;
-            if (off_hi) *off_hi = (int)off;
-            off += (1ll << (log2Ntw - log2lo)) * SZ;
-        } else if (off_hi) {
-            *off_hi = (int)off;
-        }
+        p.off_tables = (int)off;
+        off += (long long)layout_tables(p) * SZ;
         return off > 0x7fffffff ? 0x7fffffff : (int)off;
     }
 
-    // choose the column count of a tile: first reach a 128-byte row segment, then >= 256 threads
+    // Choose the tile width C (columns per tile; all of them live in LDS at once, H = 1):
+    //  - threads = (C/V) * (L/E) <= 512 (the kernel is built for 2 waves per SIMD = 8 waves per CU);
+    //  - LDS <= the per-workgroup limit;
+    //  - stop widening once the row segment reaches 512 bytes (no measurable gain beyond, tools/membench).
     static bool choose_tile(PassDesc& p, long long extent_cols, int budget) {
         const int log2E = ilog2(p.E);
-        int best = -1;
-        for (int lc = ilog2(V); (1ll << lc) <= extent_cols || lc == ilog2(V); lc++) {
-            const long long threads = (1ll << (lc - ilog2(V))) << (p.log2L - log2E);
-            if (threads > 512) break;
-            int b = lds_bytes(p.log2L, lc, p.loadm, p.storem, p.twiddle, p.log2Ntw, nullptr, nullptr, nullptr);
-            if (b > budget) break;
-            best = lc;
-            const bool seg_ok = ((1ll << lc) * SZ) >= 128;
-            if (seg_ok && threads >= 256) break;
+        const int log2V = ilog2(V);
+        int best = -1, best_levels = 2;
+        for (int levels = 2; levels <= 3; levels++) {
+            p.tw_levels = levels;
+            int cand = -1;
+            for (int lc = log2V; (1ll << lc) <= extent_cols || lc == log2V; lc++) {
+                const long long threads = (1ll << (lc - log2V)) << (p.log2L - log2E);
+                if (threads > 512) break;
+                if (lds_bytes(p, lc) > budget) break;
+                cand = lc;
+                if ((1ll << lc) * SZ >= 512 && threads >= 256) break;
+            }
+            if (cand > best) { best = cand; best_levels = levels; }
+            if (!p.twiddle) break;
         }
         if (best < 0) return false;
+        p.tw_levels = best_levels;
+        p.log2H = 0;
         p.log2C = best;
-        p.nthreads = (int)((1ll << (best - ilog2(V))) << (p.log2L - log2E));
-        p.smem_bytes = lds_bytes(p.log2L, best, p.loadm, p.storem, p.twiddle, p.log2Ntw, &p.off_tw_stage, &p.off_tw_lo,
-                                 &p.off_tw_hi);
-        long long seg = (1ll << best) * SZ;
+        p.nthreads = (int)((1ll << (best - log2V)) << (p.log2L - log2E));
+        p.smem_bytes = lds_bytes(p, best);
+        long long seg = (1ll << p.log2C) * SZ;
         p.seg_bytes = (int)(seg > 1 << 20 ? 1 << 20 : seg);
         return true;
     }
@@ -200,7 +233,7 @@ class Pow2Plan {
         if (n_force <= 1) {
             PassDesc p;
             p.log2L = log2n;
-            p.E = n < 16 ? (int)n : 16;
+            p.E = tile_E(n);
             p.loadm = fftk::LOAD_LCONTIG;
             p.storem = fftk::STORE_LCONTIG;
             p.in_c = n; p.in_l = 1; p.out_c = n; p.out_k = 1;
@@ -218,12 +251,12 @@ class Pow2Plan {
             const int l2 = log2n - l1;
             if (n_force >= 1 && !(n_force == 2 && force[0] == l1)) continue;
             PassDesc a, b;
-            a.log2L = l1; a.loadm = fftk::LOAD_CCONTIG; a.storem = fftk::STORE_CCONTIG; a.twiddle = 1; a.log2Ntw = log2n;
+            a.log2L = l1; a.E = tile_E(1ll << l1); a.loadm = fftk::LOAD_CCONTIG; a.storem = fftk::STORE_CCONTIG; a.twiddle = 1; a.log2Ntw = log2n;
             a.in_b = n; a.in_c = 1; a.in_l = 1ll << l2; a.out_b = n; a.out_c = 1; a.out_k = 1ll << l2;
             a.n_cols = 1 << l2;
             if (!choose_tile(a, 1ll << l2, budget)) continue;
             a.n_ct = (1 << l2) >> a.log2C;
-            b.log2L = l2; b.loadm = fftk::LOAD_LCONTIG; b.storem = fftk::STORE_CCONTIG;
+            b.log2L = l2; b.E = tile_E(1ll << l2); b.loadm = fftk::LOAD_LCONTIG; b.storem = fftk::STORE_CCONTIG;
             b.in_b = n; b.in_c = 1ll << l2; b.in_l = 1; b.out_b = n; b.out_c = 1; b.out_k = 1ll << l1;
             b.n_cols = 1 << l1;
             if (!choose_tile(b, 1ll << l1, budget)) continue;
@@ -245,18 +278,18 @@ class Pow2Plan {
                     if (n_force >= 1 && !(n_force == 3 && force[0] == l1 && force[1] == l2)) continue;
                     const long long M = 1ll << (l2 + l3);
                     PassDesc a, m, b;
-                    a.log2L = l1; a.loadm = fftk::LOAD_CCONTIG; a.storem = fftk::STORE_CCONTIG; a.twiddle = 1; a.log2Ntw = log2n;
+                    a.log2L = l1; a.E = tile_E(1ll << l1); a.loadm = fftk::LOAD_CCONTIG; a.storem = fftk::STORE_CCONTIG; a.twiddle = 1; a.log2Ntw = log2n;
                     a.in_b = n; a.in_c = 1; a.in_l = M; a.out_b = n; a.out_c = 1; a.out_k = M;
                     a.n_cols = (int)M;
                     if (!choose_tile(a, M, budget)) continue;
                     a.n_ct = (int)(M >> a.log2C);
-                    m.log2L = l2; m.loadm = fftk::LOAD_CCONTIG; m.storem = fftk::STORE_CCONTIG; m.twiddle = 1; m.log2Ntw = l2 + l3;
+                    m.log2L = l2; m.E = tile_E(1ll << l2); m.loadm = fftk::LOAD_CCONTIG; m.storem = fftk::STORE_CCONTIG; m.twiddle = 1; m.log2Ntw = l2 + l3;
                     m.n_b_per_transform = 1ll << l1;
                     m.in_b = M; m.in_c = 1; m.in_l = 1ll << l3; m.out_b = M; m.out_c = 1; m.out_k = 1ll << l3;
                     m.n_cols = 1 << l3;
                     if (!choose_tile(m, 1ll << l3, budget)) continue;
                     m.n_ct = (1 << l3) >> m.log2C;
-                    b.log2L = l3; b.loadm = fftk::LOAD_LCONTIG; b.storem = fftk::STORE_CCONTIG;
+                    b.log2L = l3; b.E = tile_E(1ll << l3); b.loadm = fftk::LOAD_LCONTIG; b.storem = fftk::STORE_CCONTIG;
                     b.n_o = 1 << l2;
                     b.in_b = n; b.in_o = 1ll << l3; b.in_c = M; b.in_l = 1;
                     b.out_b = n; b.out_o = 1ll << l1; b.out_c = 1; b.out_k = 1ll << (l1 + l2);
@@ -277,34 +310,35 @@ class Pow2Plan {
         if (best.empty()) return false;
         passes = best;
 
-        // ---- tables
+        // ---- tables: one blob per pass, laid out exactly as the kernel keeps it in LDS
         for (auto& p : passes) {
-            if (!stage_tables.count(p.log2L)) {
-                std::vector<cpx<T>> t;
-                make_twiddle_table<T>(t, 1ll << p.log2L, 1ll << p.log2L, 1);
-                cpx<T>* d = (cpx<T>*)rt->dmalloc(t.size() * SZ);
-                if (!d) return false;
-                rt->h2d(d, t.data(), t.size() * SZ);
-                stage_tables[p.log2L] = d;
+            layout_tables(p);
+            std::vector<cpx<T>> blob((size_t)p.tables_elems), part;
+            for (auto& z : blob) { z.re = (T)1; z.im = (T)0; }
+            const long long L = 1ll << p.log2L;
+            make_twiddle_table<T>(part, L, 1ll << p.sa_bits, 1);
+            std::copy(part.begin(), part.end(), blob.begin());
+            make_twiddle_table<T>(part, L, 1ll << (p.log2L - p.sa_bits), 1ll << p.sa_bits);
+            std::copy(part.begin(), part.end(), blob.begin() + p.o_sb);
+            if (p.twiddle) {
+                const long long Ntw = 1ll << p.log2Ntw;
+                make_twiddle_table<T>(part, Ntw, 1ll << p.t0_bits, 1);
+                std::copy(part.begin(), part.end(), blob.begin() + p.o_t0);
+                make_twiddle_table<T>(part, Ntw, 1ll << p.t1_bits, 1ll << p.t0_bits);
+                std::copy(part.begin(), part.end(), blob.begin() + p.o_t1);
+                make_twiddle_table<T>(part, Ntw, 1ll << p.t2_bits, 1ll << (p.t0_bits + p.t1_bits));
+                std::copy(part.begin(), part.end(), blob.begin() + p.o_t2);
             }
-            if (p.twiddle && !pair_tables.count(p.log2Ntw)) {
-                const int log2lo = (p.log2Ntw + 1) / 2;
-                std::vector<cpx<T>> lo, hi;
-                make_twiddle_table<T>(lo, 1ll << p.log2Ntw, 1ll << log2lo, 1);
-                make_twiddle_table<T>(hi, 1ll << p.log2Ntw, 1ll << (p.log2Ntw - log2lo), 1ll << log2lo);
-                cpx<T>* dlo = (cpx<T>*)rt->dmalloc(lo.size() * SZ);
-                cpx<T>* dhi = (cpx<T>*)rt->dmalloc(hi.size() * SZ);
-                if (!dlo || !dhi) return false;
-                rt->h2d(dlo, lo.data(), lo.size() * SZ);
-                rt->h2d(dhi, hi.data(), hi.size() * SZ);
-                pair_tables[p.log2Ntw] = std::make_pair(dlo, dhi);
-            }
+            cpx<T>* d = (cpx<T>*)rt->dmalloc(blob.size() * SZ);
+            if (!d) return false;
+            rt->h2d(d, blob.data(), blob.size() * SZ);
+            pass_tables.push_back(d);
         }
 
         // ---- Infinity-Cache blocking of the batch (multi-pass only)
         chunk = batch;
         if (passes.size() > 1) {
-            long long target = 64ll << 20;  // bytes of scratch kept hot between passes
+            long long target = 1024ll << 20;  // scratch bytes per launch group (FFT_HIP_CHUNK_MB); see DESIGN.md on the Infinity Cache
             if (const char* e = getenv("FFT_HIP_CHUNK_MB")) {
                 long long mb = atoll(e);
                 if (mb > 0) target = mb << 20;
@@ -324,63 +358,69 @@ class Pow2Plan {
 
     template <int E, int FAM, int LM, int SM, bool TW>
     void launch_one(const fftk::TileParams<T>& tp, long long grid, const PassDesc& p) {
-        rt->launch(fftk::tile_fft_kernel<T, E, FAM, LM, SM, TW>, grid, p.nthreads, (size_t)p.smem_bytes, tp);
+        rt->launch(fftk::tile_fft_kernel<T, E, 1, FAM, LM, SM, TW, 0>, grid, p.nthreads, (size_t)p.smem_bytes, tp);
     }
 
-    template <int FAM>
-    void launch_fam(const fftk::TileParams<T>& tp, long long grid, const PassDesc& p) {
+    template <int FAM, int LM, int SM, bool TW>
+    void launch_mode(const fftk::TileParams<T>& tp, long long grid, const PassDesc& p) {
         using namespace fftk;
-        if (p.loadm == LOAD_CCONTIG) {
-            launch_one<16, FAM, LOAD_CCONTIG, STORE_CCONTIG, true>(tp, grid, p);
-        } else if (p.storem == STORE_CCONTIG) {
-            launch_one<16, FAM, LOAD_LCONTIG, STORE_CCONTIG, false>(tp, grid, p);
-        } else {
-            switch (p.E) {
-                case 2: launch_one<2, FAM_R2, LOAD_LCONTIG, STORE_LCONTIG, false>(tp, grid, p); break;
-                case 4: launch_one<4, (FAM == FAM_SR16 ? FAM_R4 : FAM), LOAD_LCONTIG, STORE_LCONTIG, false>(tp, grid, p); break;
-                case 8: launch_one<8, FAM, LOAD_LCONTIG, STORE_LCONTIG, false>(tp, grid, p); break;
-                default: launch_one<16, FAM, LOAD_LCONTIG, STORE_LCONTIG, false>(tp, grid, p); break;
-            }
+        switch (p.E) {
+            case 2: launch_one<2, FAM_R2, LM, SM, TW>(tp, grid, p); break;
+            case 4: launch_one<4, (FAM == FAM_SR16 ? FAM_R4 : FAM), LM, SM, TW>(tp, grid, p); break;
+            case 8: launch_one<8, FAM, LM, SM, TW>(tp, grid, p); break;
+            default: launch_one<16, FAM, LM, SM, TW>(tp, grid, p); break;
         }
     }
 
-    void launch_pass(const PassDesc& p, const cpx<T>* in, cpx<T>* out, int nb, bool inverse, T scale) {
+    template <int FAM, int H>
+    void launch_fam(const fftk::TileParams<T>& tp, long long grid, const PassDesc& p) {
+        using namespace fftk;
+        if (p.loadm == LOAD_CCONTIG) launch_mode<FAM, LOAD_CCONTIG, STORE_CCONTIG, true>(tp, grid, p);
+        else if (p.storem == STORE_CCONTIG) launch_mode<FAM, LOAD_LCONTIG, STORE_CCONTIG, false>(tp, grid, p);
+        else launch_mode<FAM, LOAD_LCONTIG, STORE_LCONTIG, false>(tp, grid, p);
+    }
+
+    void launch_pass(size_t ipass, const cpx<T>* in, cpx<T>* out, int nb, bool inverse, T scale) {
+        const PassDesc& p = passes[ipass];
         fftk::TileParams<T> tp;
         memset(&tp, 0, sizeof(tp));
         tp.in = in;
         tp.out = out;
-        tp.tw_stage = stage_tables[p.log2L];
-        if (p.twiddle) {
-            tp.tw_lo = pair_tables[p.log2Ntw].first;
-            tp.tw_hi = pair_tables[p.log2Ntw].second;
-            tp.tw_log2lo = (p.log2Ntw + 1) / 2;
-            tp.tw_lo_len = 1 << tp.tw_log2lo;
-            tp.tw_hi_len = 1 << (p.log2Ntw - tp.tw_log2lo);
-        }
+        tp.tables = pass_tables[ipass];
+        tp.tables_bytes = p.tables_elems * SZ;
+        tp.off_tables = p.off_tables;
+        tp.o_sb = p.o_sb; tp.o_t0 = p.o_t0; tp.o_t1 = p.o_t1; tp.o_t2 = p.o_t2;
+        tp.sa_bits = p.sa_bits; tp.t0_bits = p.t0_bits; tp.t1_bits = p.t1_bits; tp.t2_bits = p.t2_bits;
         tp.log2L = p.log2L;
         tp.log2C = p.log2C;
         tp.n_ct = p.n_ct;
         tp.n_o = p.n_o;
         tp.in_b = p.in_b; tp.in_o = p.in_o; tp.in_c = p.in_c; tp.in_l = p.in_l;
         tp.out_b = p.out_b; tp.out_o = p.out_o; tp.out_c = p.out_c; tp.out_k = p.out_k;
-        tp.off_tw_stage = p.off_tw_stage; tp.off_tw_lo = p.off_tw_lo; tp.off_tw_hi = p.off_tw_hi;
         tp.inverse = inverse ? 1 : 0;
         tp.scale = scale;
         static const int ablate = getenv("FFT_HIP_ABLATE") ? atoi(getenv("FFT_HIP_ABLATE")) : 0;  // profiling only
         tp.ablate = ablate;
-        long long grid;
         if (p.n_cols < 0) {  // single-pass row kernel: columns are the transforms of the batch
             tp.n_cols = nb;
             tp.n_ct = (int)((nb + (1ll << p.log2C) - 1) >> p.log2C);
-            grid = tp.n_ct;
+            tp.n_tiles = tp.n_ct;
         } else {
             tp.n_cols = p.n_cols;
-            grid = (long long)nb * p.n_b_per_transform * p.n_o * p.n_ct;
+            tp.n_tiles = (long long)nb * p.n_b_per_transform * p.n_o * p.n_ct;
         }
+        // persistent grid: as many workgroups as stay resident (8 waves per CU), each walks n_tiles / grid tiles
+        int per_cu = 512 / p.nthreads;
+        const int by_lds = rt->max_lds_bytes() / (p.smem_bytes > 0 ? p.smem_bytes : 1);
+        if (per_cu > by_lds) per_cu = by_lds;
+        if (per_cu < 1) per_cu = 1;
+        static const int tiles_per_wg_min = getenv("FFT_HIP_NONPERSISTENT") ? 0 : 1;
+        long long grid = (long long)rt->num_cus() * per_cu;
+        if (!tiles_per_wg_min || grid > tp.n_tiles) grid = tp.n_tiles;
         switch (fam) {
-            case fftk::FAM_R2: launch_fam<fftk::FAM_R2>(tp, grid, p); break;
-            case fftk::FAM_R4: launch_fam<fftk::FAM_R4>(tp, grid, p); break;
-            default: launch_fam<fftk::FAM_SR16>(tp, grid, p); break;
+            case fftk::FAM_R2: launch_fam<fftk::FAM_R2, 1>(tp, grid, p); break;
+            case fftk::FAM_R4: launch_fam<fftk::FAM_R4, 1>(tp, grid, p); break;
+            default: launch_fam<fftk::FAM_SR16, 1>(tp, grid, p); break;
         }
     }
 
@@ -409,7 +449,7 @@ class Pow2Plan {
             return;
         }
         if (passes.size() == 1) {
-            launch_pass(passes[0], in, out, nb, inverse, scale);
+            launch_pass(0, in, out, nb, inverse, scale);
             return;
         }
         for (int b0 = 0; b0 < nb; b0 += chunk) {
@@ -417,12 +457,12 @@ class Pow2Plan {
             const cpx<T>* src = in + (size_t)b0 * (size_t)n;
             cpx<T>* dst = out + (size_t)b0 * (size_t)n;
             if (passes.size() == 2) {
-                launch_pass(passes[0], src, scratch, cb, inverse, (T)1);
-                launch_pass(passes[1], scratch, dst, cb, inverse, scale);
+                launch_pass(0, src, scratch, cb, inverse, (T)1);
+                launch_pass(1, scratch, dst, cb, inverse, scale);
             } else {
-                launch_pass(passes[0], src, scratch, cb, inverse, (T)1);
-                launch_pass(passes[1], scratch, scratch, cb, inverse, (T)1);
-                launch_pass(passes[2], scratch, dst, cb, inverse, scale);
+                launch_pass(0, src, scratch, cb, inverse, (T)1);
+                launch_pass(1, scratch, scratch, cb, inverse, (T)1);
+                launch_pass(2, scratch, dst, cb, inverse, scale);
             }
         }
     }

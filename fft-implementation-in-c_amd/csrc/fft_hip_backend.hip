@@ -35,6 +35,7 @@ namespace {
 struct HipRT {
     hipStream_t stream = nullptr;
     int lds_limit = 64 * 1024;
+    int cus = 256;
     std::set<const void*> configured;
 
     void* dmalloc(size_t bytes) {
@@ -51,6 +52,7 @@ struct HipRT {
     }
     void h2d(void* dst, const void* src, size_t bytes) { (void)hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice); }
     int max_lds_bytes() { return lds_limit; }
+    int num_cus() { return cus; }
 
     template <class K, class... A>
     void launch(K kernel, long long grid, int block, size_t smem, A... args) {
@@ -70,6 +72,7 @@ int g_initialized = 0;
 int g_device = 0;
 char g_device_name[256] = "No GPU";
 int g_lds_limit = 64 * 1024;
+int g_num_cus = 256;
 
 int probe_device_count() {
     int count = 0;
@@ -180,6 +183,7 @@ int fft_gpu_init_hip(void) {
         if (v >= 16384) lds = (size_t)v;
     }
     g_lds_limit = (int)lds;
+    g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     g_initialized = 1;
     pthread_mutex_unlock(&g_lock);
     return 0;
@@ -281,6 +285,7 @@ fft_gpu_plan_t fft_gpu_plan_1d_ex_hip(int n, int batch, fft_direction dir, fft_p
     }
     p->rt.stream = p->own_stream;
     p->rt.lds_limit = g_lds_limit;
+    p->rt.cus = g_num_cus;
     bool ok = false;
     const int log2n = ffteng::ilog2(n);
     if (p->pow2) {

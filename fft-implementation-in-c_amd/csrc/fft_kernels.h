@@ -30,26 +30,37 @@ enum { FAM_SR16 = 0, FAM_R4 = 1, FAM_R2 = 2 };
 // "column FFT" of the four-step scheme, optimizations/parallel_fft.c:227-237 in
 // the reference); LOAD_LCONTIG needs in_l == 1 (each sub-transform contiguous:
 // the "row FFT", parallel_fft.c:250-261).  Same for the store side.
+//
+// The C columns are processed as H groups of CG = C/H columns: all H groups are
+// loaded (and later stored) together, so HBM sees C*sizeof(cpx)-byte row
+// segments, but only one group at a time lives in LDS.  This halves the LDS
+// footprint (two workgroups per CU: one streams HBM while the other computes)
+// without narrowing the segments.
+//
+// Twiddle tables travel as one blob, copied to LDS at kernel start:
+//   [ sa | sb | t0 | t1 | t2 ]
+//   stage twiddle     W_L^m   = sa[m & (2^sa_bits - 1)] * sb[m >> sa_bits]      (sb unused when sa_bits == log2L)
+//   inter-pass twiddle W_Ntw^m = t0[m & ..] * t1[(m >> t0_bits) & ..] * t2[m >> (t0_bits + t1_bits)]
 template <typename T>
 struct TileParams {
     const cpx<T>* in;
     cpx<T>* out;
-    const cpx<T>* tw_stage;  // W_L^m = exp(-2 pi i m / L), m in [0, L)
-    const cpx<T>* tw_lo;     // inter-pass twiddle, two-level: W_Ntw^m = tw_lo[m & (LO-1)] * tw_hi[m >> log2LO]
-    const cpx<T>* tw_hi;
+    const cpx<T>* tables;  // device copy of the blob
+    int tables_bytes;      // multiple of 16
+    int off_tables;        // byte offset of the blob's LDS copy
+    int o_sb, o_t0, o_t1, o_t2;  // element offsets inside the blob (sa at 0)
+    int sa_bits, t0_bits, t1_bits, t2_bits;
     int log2L;
-    int log2C;
-    int n_ct;  // column tiles per (b, o)
+    int log2C;  // all H groups together
+    int n_ct;   // column tiles per (b, o)
     int n_o;
     long long in_b, in_o, in_c, in_l;
     long long out_b, out_o, out_c, out_k;
-    int n_cols;  // columns >= n_cols are padding (read as zero, never stored)
-    int tw_log2lo;
-    int tw_lo_len, tw_hi_len;
-    int off_tw_stage, off_tw_lo, off_tw_hi;  // byte offsets of the LDS copies of the tables
-    int inverse;                             // 1: inverse transform via the re<->im swap identity
-    int ablate;                              // profiling only (FFT_HIP_ABLATE): 1 skip inter-pass twiddle, 2 skip stages, 4 skip stage twiddles
-    T scale;                                 // applied at the store (1/N folded into the last pass)
+    long long n_tiles;  // tiles of this launch; a workgroup walks tiles blockIdx, blockIdx + gridDim, ...
+    int n_cols;   // columns >= n_cols are padding (read as zero, never stored)
+    int inverse;  // 1: inverse transform via the re<->im swap identity
+    int ablate;   // profiling only (FFT_HIP_ABLATE): 1 skip inter-pass twiddle, 2 skip stages
+    T scale;      // applied at the store (1/N folded into the last pass)
 };
 
 template <int X>
@@ -59,6 +70,19 @@ struct Log2 {
 template <>
 struct Log2<1> {
     static constexpr int value = 0;
+};
+
+template <typename T>
+struct StageTw {
+    const cpx<T>* sa;
+    const cpx<T>* sb;
+    int sa_bits;
+    int log2L;
+    FFT_DEVICE cpx<T> get(int m) const {
+        m &= (1 << log2L) - 1;
+        if (sa_bits >= log2L) return sa[m];  // wave-uniform: single-level table (<= 8 KiB)
+        return cmul(sa[m & ((1 << sa_bits) - 1)], sb[m >> sa_bits]);
+    }
 };
 
 // ---------------------------------------------------------------------------
@@ -74,8 +98,8 @@ struct Log2<1> {
 // the inputs were loaded in, so a c-contiguous store needs no further exchange.
 // ---------------------------------------------------------------------------
 template <typename T, int E, int R, int V>
-FFT_DEVICE void stockham_stage(cpx<T> (&x)[E][V], unsigned char* smem, const cpx<T>* tws, int r, int j, int log2J,
-                               int log2TPC, int log2L, int& log2Lprev, int& log2P, bool first, bool last) {
+FFT_DEVICE void stockham_stage(cpx<T> (&x)[E][V], unsigned char* smem, const StageTw<T>& tw, int r, int j, int log2J,
+                               int log2TPC, int& log2Lprev, int& log2P, bool first, bool last) {
     constexpr int G = E / R;
     constexpr int log2R = Log2<R>::value;
     const int log2Li = log2Lprev - log2R;
@@ -112,7 +136,6 @@ FFT_DEVICE void stockham_stage(cpx<T> (&x)[E][V], unsigned char* smem, const cpx
     }
 
     if (!last) {
-        const int Lmask = (1 << log2L) - 1;
         FFT_UNROLL
         for (int m = 0; m < G; m++) {
             const int u = r + (m << log2TPC);
@@ -120,12 +143,12 @@ FFT_DEVICE void stockham_stage(cpx<T> (&x)[E][V], unsigned char* smem, const cpx
             const int tq = q << log2P;
             FFT_UNROLL
             for (int k = 1; k < R; k++) {
-                const cpx<T> w = tws[(tq * k) & Lmask];
+                const cpx<T> w = tw.get(tq * k);
                 FFT_UNROLL
                 for (int vv = 0; vv < V; vv++) x[m + G * k][vv] = cmul(x[m + G * k][vv], w);
             }
         }
-        if (!first) FFT_SYNC();  // everyone has finished reading the previous exchange
+        if (!first) FFT_SYNC_LDS();  // everyone has finished reading the previous exchange
         FFT_UNROLL
         for (int m = 0; m < G; m++) {
             const int u = r + (m << log2TPC);
@@ -140,187 +163,317 @@ FFT_DEVICE void stockham_stage(cpx<T> (&x)[E][V], unsigned char* smem, const cpx
                 data[(idx << log2J) + j] = v;
             }
         }
-        FFT_SYNC();
+        FFT_SYNC_LDS();
     }
     log2Lprev = log2Li;
     log2P += log2R;
 }
 
+// All stages of one tile.  `before_last` runs once, right before the LAST stage reads its inputs from
+// LDS (or before the only stage): at that point the thread's data registers are dead (everything sits in
+// LDS), which is where the kernel issues the next tile's prefetch without raising the register peak.
+template <typename T, int E, int FAM, int V, class F>
+FFT_DEVICE void stockham_all_stages(cpx<T> (&x)[E][V], unsigned char* smem, const StageTw<T>& tw, int r, int j,
+                                    int log2J, int log2TPC, int log2L, F&& before_last) {
+    constexpr int RM = (FAM == FAM_SR16) ? E : (FAM == FAM_R4 ? (E < 4 ? E : 4) : 2);
+    constexpr int log2RM = Log2<RM>::value;
+    int log2Lprev = log2L, log2P = 0;
+    const int n_full = log2L / log2RM;
+    const int rem = log2L - n_full * log2RM;
+    const int total = n_full + (rem ? 1 : 0);
+    FFT_UNROLL
+    for (int s = 0; s < n_full; s++) {
+        if (s == total - 1) before_last();
+        stockham_stage<T, E, RM, V>(x, smem, tw, r, j, log2J, log2TPC, log2Lprev, log2P, s == 0, s == total - 1);
+    }
+    if (rem) before_last();
+    if (RM > 2 && rem == 1)
+        stockham_stage<T, E, 2, V>(x, smem, tw, r, j, log2J, log2TPC, log2Lprev, log2P, total == 1, true);
+    if (RM > 4 && rem == 2)
+        stockham_stage<T, E, (RM > 4 ? 4 : 2), V>(x, smem, tw, r, j, log2J, log2TPC, log2Lprev, log2P, total == 1, true);
+    if (RM > 8 && rem == 3)
+        stockham_stage<T, E, (RM > 8 ? 8 : 2), V>(x, smem, tw, r, j, log2J, log2TPC, log2Lprev, log2P, total == 1, true);
+}
+
 // ---------------------------------------------------------------------------
-// The tile kernel.  Thread (j, r): j = tid mod J selects V adjacent columns
-// (J = C/V lanes cover one 16*J-byte row segment), r = tid div J in [0, L/E)
-// selects which E elements of those columns the thread owns.
+// The tile kernel.  Thread (j, r): j = tid mod J selects V adjacent columns of
+// each group (J = CG/V lanes cover one 16*J-byte row segment of a group),
+// r = tid div J in [0, L/E) selects which E elements of those columns the
+// thread owns.  nthreads == J * L/E exactly.
+//
+// PERSISTENT + PREFETCH: a workgroup walks tiles blockIdx, blockIdx + gridDim,
+// ...; the 16-byte loads of the NEXT tile are issued into `nxt` before the
+// current tile's stages run, and every barrier inside the stages is LDS-only
+// (FFT_SYNC_LDS leaves vmcnt alone), so each CU keeps HBM reads in flight while
+// it computes.  A CU can only sustain ~20 GB/s of misses (latency x outstanding
+// lines); without this overlap the load, compute and store phases of a tile
+// simply add up (measured: copy-only 3.8 ms + stages 1.6 ms + twiddle 0.4 ms).
 // ---------------------------------------------------------------------------
-template <typename T, int E, int FAM, int LOADM, int STOREM, bool TWIDDLE>
-FFT_KERNEL void FFT_LAUNCH_BOUNDS(512) tile_fft_kernel(TileParams<T> p) {
+template <typename T>
+struct TileCoord {
+    const cpx<T>* in;
+    cpx<T>* out;
+    int c0;
+};
+
+template <typename T>
+FFT_DEVICE TileCoord<T> tile_coord(const TileParams<T>& p, long long tile) {
+    TileCoord<T> tc;
+    const unsigned t32 = (unsigned)tile;  // launches never exceed 2^31 tiles
+    const unsigned ct = t32 % (unsigned)p.n_ct;
+    const unsigned rest = t32 / (unsigned)p.n_ct;
+    const unsigned o = rest % (unsigned)p.n_o;
+    const long long b = rest / (unsigned)p.n_o;
+    tc.c0 = ct << p.log2C;
+    tc.in = p.in + b * p.in_b + o * p.in_o + (long long)tc.c0 * p.in_c;
+    tc.out = p.out + b * p.out_b + o * p.out_o + (long long)tc.c0 * p.out_c;
+    return tc;
+}
+
+// FIXED != 0 bakes (log2L << 8 | log2C) into the instantiation: every LDS offset becomes an immediate and the
+// stage loop unrolls (fewer address VGPRs, less integer VALU); FIXED == 0 reads both from the parameters.
+template <typename T, int E, int H, int FAM, int LOADM, int STOREM, bool TWIDDLE, int FIXED>
+FFT_KERNEL void FFT_LAUNCH_BOUNDS2(512, 2) tile_fft_kernel(TileParams<T> p) {
     constexpr int V = vec16<T>::V;
     constexpr int log2V = Log2<V>::value;
     constexpr int log2E = Log2<E>::value;
-    constexpr int RM = (FAM == FAM_SR16) ? E : (FAM == FAM_R4 ? (E < 4 ? E : 4) : 2);
-    constexpr int log2RM = Log2<RM>::value;
+    constexpr int log2H = Log2<H>::value;
     constexpr int SZ = (int)sizeof(cpx<T>);
     FFT_DYN_SMEM(smem);
 
     const int tid = FFT_TID;
     const int nthreads = FFT_NTHREADS;
-    const int log2L = p.log2L;
+    const int log2L = FIXED ? (FIXED >> 8) : p.log2L;
+    const int log2C = FIXED ? (FIXED & 255) : p.log2C;
     const int L = 1 << log2L;
     const int log2TPC = log2L - log2E;
-    const int log2J = p.log2C - log2V;
+    const int log2CG = log2C - log2H;
+    const int CG = 1 << log2CG;
+    const int log2J = log2CG - log2V;
     const int J = 1 << log2J;
-    const int C = 1 << p.log2C;
     const int j = tid & (J - 1);
     const int r = tid >> log2J;
+    const long long n_tiles = p.n_tiles;
+    const long long tile_step = FFT_NBLOCKS;
+
+    // ---- tables -> LDS ("twiddles staged in LDS"), once per workgroup
+    {
+        const vec16<T>* src = reinterpret_cast<const vec16<T>*>(p.tables);
+        vec16<T>* dst = reinterpret_cast<vec16<T>*>(smem + p.off_tables);
+        for (int i = tid; i < (p.tables_bytes >> 4); i += nthreads) dst[i] = src[i];
+    }
+    const cpx<T>* tab = reinterpret_cast<const cpx<T>*>(smem + p.off_tables);
+    StageTw<T> tw;
+    tw.sa = tab;
+    tw.sb = tab + p.o_sb;
+    tw.sa_bits = p.sa_bits;
+    tw.log2L = log2L;
+
+    const int pitch = L * SZ + 16;      // raw-row pitch of the l-contiguous staging image
+    const int log2CPR = log2L - log2V;  // 16-byte chunks per row (L >= V always)
+    const int cpr_mask = (1 << log2CPR) - 1;
+
+    // nxt[h][i]: the 16-byte lane loads of a tile, in flight or landed.
+    //   LOAD_CCONTIG: nxt[h][e] = element l = r + TPC*e of columns h*CG + V*j + (0..V-1)
+    //   LOAD_LCONTIG: nxt[h][i] = chunk g = tid + i*nthreads of the group's contiguous rows
+    //                 (CG rows * L/V chunks == nthreads * E, so every thread moves exactly E chunks)
+    vec16<T> nxt[H][E];
+    auto prefetch = [&](long long tile) {
+        const TileCoord<T> tc = tile_coord(p, tile);
+        FFT_UNROLL
+        for (int h = 0; h < H; h++) {
+            FFT_UNROLL
+            for (int i = 0; i < E; i++) {
+                bool live;
+                const cpx<T>* src;
+                if (LOADM == LOAD_CCONTIG) {
+                    const long long l = r + ((long long)i << log2TPC);
+                    live = (tc.c0 + h * CG + V * j) < p.n_cols;
+                    src = tc.in + l * p.in_l + h * CG + V * j;
+                } else {
+                    const int g = tid + i * nthreads;
+                    const int t = h * CG + (g >> log2CPR);
+                    live = (tc.c0 + t) < p.n_cols;
+                    src = tc.in + (long long)t * p.in_c + (long long)(g & cpr_mask) * V;
+                }
+                if (live) {
+                    nxt[h][i] = *reinterpret_cast<const vec16<T>*>(src);
+                } else {
+                    FFT_UNROLL
+                    for (int vv = 0; vv < V; vv++) nxt[h][i].c[vv] = mk<T>((T)0, (T)0);
+                }
+            }
+        }
+    };
 
     long long tile = FFT_BID;
-    const int ct = (int)(tile % p.n_ct);
-    tile /= p.n_ct;
-    const int o = (int)(tile % p.n_o);
-    const long long b = tile / p.n_o;
-    const int c0 = ct * C;
-    const cpx<T>* in = p.in + b * p.in_b + o * p.in_o + (long long)c0 * p.in_c;
-    cpx<T>* out = p.out + b * p.out_b + o * p.out_o + (long long)c0 * p.out_c;
+    if (tile < n_tiles) prefetch(tile);
+    FFT_SYNC();  // tables visible (also drains the first prefetch; steady state uses LDS-only barriers)
 
-    // ---- tables -> LDS ("twiddles staged in LDS")
-    cpx<T>* tws = reinterpret_cast<cpx<T>*>(smem + p.off_tw_stage);
-    for (int i = tid; i < L; i += nthreads) tws[i] = p.tw_stage[i];
-    cpx<T>* tlo = reinterpret_cast<cpx<T>*>(smem + p.off_tw_lo);
-    cpx<T>* thi = reinterpret_cast<cpx<T>*>(smem + p.off_tw_hi);
-    if (TWIDDLE) {
-        for (int i = tid; i < p.tw_lo_len; i += nthreads) tlo[i] = p.tw_lo[i];
-        for (int i = tid; i < p.tw_hi_len; i += nthreads) thi[i] = p.tw_hi[i];
-    }
+    for (; tile < n_tiles; tile += tile_step) {
+        const TileCoord<T> tc = tile_coord(p, tile);
+        cpx<T> x[H][E][V];
 
-    const int pitch = L * SZ + 16;  // raw-row pitch of the l-contiguous staging image
-    const int log2CPR = log2L - log2V;  // 16-byte chunks per row (L >= V always)
-
-    // ---- load: slot e <- element l = r + TPC*e of the thread's V columns
-    cpx<T> x[E][V];
-    if (LOADM == LOAD_CCONTIG) {
-        const bool live = (c0 + V * j) < p.n_cols;
-        FFT_UNROLL
-        for (int e = 0; e < E; e++) {
-            const long long l = r + ((long long)e << log2TPC);
-            vec16<T> v;
-            if (live) {
-                v = *reinterpret_cast<const vec16<T>*>(in + l * p.in_l + V * j);
-            } else {
+        // ---- consume the landed loads: slot e of group h <- element l = r + TPC*e
+        if (LOADM == LOAD_CCONTIG) {
+            FFT_UNROLL
+            for (int h = 0; h < H; h++) {
                 FFT_UNROLL
-                for (int vv = 0; vv < V; vv++) v.c[vv] = mk<T>((T)0, (T)0);
+                for (int e = 0; e < E; e++) {
+                    FFT_UNROLL
+                    for (int vv = 0; vv < V; vv++) x[h][e][vv] = nxt[h][e].c[vv];
+                }
             }
+        } else {
             FFT_UNROLL
-            for (int vv = 0; vv < V; vv++) x[e][vv] = v.c[vv];
-        }
-        FFT_SYNC();  // tables visible
-    } else {
-        const int total = C << log2CPR;
-        for (int g = tid; g < total; g += nthreads) {
-            const int t = g >> log2CPR;
-            const int pos = g & ((1 << log2CPR) - 1);
-            vec16<T> v;
-            if (c0 + t < p.n_cols) {
-                v = *reinterpret_cast<const vec16<T>*>(in + (long long)t * p.in_c + (long long)pos * V);
-            } else {
+            for (int h = 0; h < H; h++) {
+                FFT_SYNC_LDS();  // the previous user of the exchange area (last tile's store image / previous group) is done
                 FFT_UNROLL
-                for (int vv = 0; vv < V; vv++) v.c[vv] = mk<T>((T)0, (T)0);
-            }
-            *reinterpret_cast<vec16<T>*>(smem + (size_t)t * pitch + (size_t)pos * 16) = v;
-        }
-        FFT_SYNC();
-        FFT_UNROLL
-        for (int e = 0; e < E; e++) {
-            const int l = r + (e << log2TPC);
-            FFT_UNROLL
-            for (int vv = 0; vv < V; vv++)
-                x[e][vv] = *reinterpret_cast<const cpx<T>*>(smem + (size_t)(V * j + vv) * pitch + (size_t)l * SZ);
-        }
-        FFT_SYNC();  // staging image is dead; the exchange area may overwrite it
-    }
-    if (p.inverse) {
-        FFT_UNROLL
-        for (int e = 0; e < E; e++) {
-            FFT_UNROLL
-            for (int vv = 0; vv < V; vv++) x[e][vv] = cswap(x[e][vv]);
-        }
-    }
-
-    // ---- stages
-    if (!(p.ablate & 2)) {
-        int log2Lprev = log2L, log2P = 0;
-        const int n_full = log2L / log2RM;
-        const int rem = log2L - n_full * log2RM;
-        const int total = n_full + (rem ? 1 : 0);
-        for (int s = 0; s < n_full; s++)
-            stockham_stage<T, E, RM, V>(x, smem, tws, r, j, log2J, log2TPC, log2L, log2Lprev, log2P, s == 0,
-                                        s == total - 1);
-        if (RM > 2 && rem == 1)
-            stockham_stage<T, E, 2, V>(x, smem, tws, r, j, log2J, log2TPC, log2L, log2Lprev, log2P, total == 1, true);
-        if (RM > 4 && rem == 2)
-            stockham_stage<T, E, (RM > 4 ? 4 : 2), V>(x, smem, tws, r, j, log2J, log2TPC, log2L, log2Lprev, log2P,
-                                                      total == 1, true);
-        if (RM > 8 && rem == 3)
-            stockham_stage<T, E, (RM > 8 ? 8 : 2), V>(x, smem, tws, r, j, log2J, log2TPC, log2L, log2Lprev, log2P,
-                                                      total == 1, true);
-    }
-
-    // ---- inter-pass twiddle W_Ntw^(K * column), scale, inverse swap
-    if (TWIDDLE && !(p.ablate & 1)) {
-        const unsigned lo_mask = (1u << p.tw_log2lo) - 1u;
-        FFT_UNROLL
-        for (int e = 0; e < E; e++) {
-            const unsigned K = (unsigned)(r + (e << log2TPC));
-            FFT_UNROLL
-            for (int vv = 0; vv < V; vv++) {
-                const unsigned m = K * (unsigned)(c0 + V * j + vv);
-                const cpx<T> w = cmul(tlo[m & lo_mask], thi[m >> p.tw_log2lo]);
-                x[e][vv] = cmul(x[e][vv], w);
+                for (int i = 0; i < E; i++) {
+                    const int g = tid + i * nthreads;
+                    *reinterpret_cast<vec16<T>*>(smem + (size_t)(g >> log2CPR) * pitch + (size_t)(g & cpr_mask) * 16) = nxt[h][i];
+                }
+                FFT_SYNC_LDS();
+                FFT_UNROLL
+                for (int e = 0; e < E; e++) {
+                    const int l = r + (e << log2TPC);
+                    FFT_UNROLL
+                    for (int vv = 0; vv < V; vv++)
+                        x[h][e][vv] = *reinterpret_cast<const cpx<T>*>(smem + (size_t)(V * j + vv) * pitch + (size_t)l * SZ);
+                }
             }
         }
-    }
-    if (p.inverse) {
-        FFT_UNROLL
-        for (int e = 0; e < E; e++) {
+        if (p.inverse) {
             FFT_UNROLL
-            for (int vv = 0; vv < V; vv++) x[e][vv] = cswap(x[e][vv]);
+            for (int h = 0; h < H; h++) {
+                FFT_UNROLL
+                for (int e = 0; e < E; e++) {
+                    FFT_UNROLL
+                    for (int vv = 0; vv < V; vv++) x[h][e][vv] = cswap(x[h][e][vv]);
+                }
+            }
         }
-    }
-    if (p.scale != (T)1) {
-        FFT_UNROLL
-        for (int e = 0; e < E; e++) {
-            FFT_UNROLL
-            for (int vv = 0; vv < V; vv++) x[e][vv] = cscale(x[e][vv], p.scale);
-        }
-    }
 
-    // ---- store: slot e holds frequency K = r + TPC*e
-    if (STOREM == STORE_CCONTIG) {
-        if ((c0 + V * j) < p.n_cols) {
+        // ---- stages, one column group at a time through the same LDS exchange area
+        // Next tile's loads.  E <= 8: a thread's tile share is 32 VGPRs, so the prefetch is issued right here and
+        // flies during ALL of this tile's stages.  E == 16 (64 + 64 VGPRs would spill under the 2-waves-per-SIMD
+        // budget): issued from inside the last group's stages, at the point where the data registers are dead.
+        constexpr bool EARLY = (E <= 8);
+        const bool have_next = (tile + tile_step) < n_tiles;
+        if (EARLY && have_next) prefetch(tile + tile_step);
+        if (!(p.ablate & 2)) {
+            FFT_UNROLL
+            for (int h = 0; h < H; h++) {
+                FFT_SYNC_LDS();  // staging image / previous group's last exchange / previous tile fully consumed
+                if (h == H - 1) {
+                    stockham_all_stages<T, E, FAM, V>(x[h], smem, tw, r, j, log2J, log2TPC, log2L, [&]() {
+                        if (!EARLY && have_next) prefetch(tile + tile_step);
+                    });
+                } else {
+                    stockham_all_stages<T, E, FAM, V>(x[h], smem, tw, r, j, log2J, log2TPC, log2L, []() {});
+                }
+            }
+        } else if (!EARLY && have_next) {
+            prefetch(tile + tile_step);
+        }
+
+        // ---- the prefetched tile has landed long ago: take the vmcnt wait now, before this tile's stores
+#ifdef FFT_EARLY_WAIT
+        if (have_next) {
+            FFT_UNROLL
+            for (int h = 0; h < H; h++) {
+                FFT_UNROLL
+                for (int i = 0; i < E; i++) {
+                    FFT_UNROLL
+                    for (int vv = 0; vv < V; vv++) {
+                        FFT_WAIT_LOADED(nxt[h][i].c[vv].re);
+                        FFT_WAIT_LOADED(nxt[h][i].c[vv].im);
+                    }
+                }
+            }
+        }
+#endif
+
+        // ---- inter-pass twiddle W_Ntw^(K * column), scale, inverse swap
+        if (TWIDDLE && !(p.ablate & 1)) {
+            const cpx<T>* t0 = tab + p.o_t0;
+            const cpx<T>* t1 = tab + p.o_t1;
+            const cpx<T>* t2 = tab + p.o_t2;
+            const unsigned m0 = (1u << p.t0_bits) - 1u, m1 = (1u << p.t1_bits) - 1u;
+            const int sh2 = p.t0_bits + p.t1_bits;
+            FFT_UNROLL
+            for (int h = 0; h < H; h++) {
+                FFT_UNROLL
+                for (int e = 0; e < E; e++) {
+                    const unsigned K = (unsigned)(r + (e << log2TPC));
+                    FFT_UNROLL
+                    for (int vv = 0; vv < V; vv++) {
+                        const unsigned m = K * (unsigned)(tc.c0 + h * CG + V * j + vv);
+                        cpx<T> w = cmul(t0[m & m0], t1[(m >> p.t0_bits) & m1]);
+                        if (p.t2_bits) w = cmul(w, t2[m >> sh2]);
+                        x[h][e][vv] = cmul(x[h][e][vv], w);
+                    }
+                }
+            }
+        }
+        if (p.inverse) {
+            FFT_UNROLL
+            for (int h = 0; h < H; h++) {
+                FFT_UNROLL
+                for (int e = 0; e < E; e++) {
+                    FFT_UNROLL
+                    for (int vv = 0; vv < V; vv++) x[h][e][vv] = cswap(x[h][e][vv]);
+                }
+            }
+        }
+        if (p.scale != (T)1) {
+            FFT_UNROLL
+            for (int h = 0; h < H; h++) {
+                FFT_UNROLL
+                for (int e = 0; e < E; e++) {
+                    FFT_UNROLL
+                    for (int vv = 0; vv < V; vv++) x[h][e][vv] = cscale(x[h][e][vv], p.scale);
+                }
+            }
+        }
+
+        // ---- store: slot e holds frequency K = r + TPC*e
+        if (STOREM == STORE_CCONTIG) {
             FFT_UNROLL
             for (int e = 0; e < E; e++) {
                 const long long K = r + ((long long)e << log2TPC);
-                vec16<T> v;
                 FFT_UNROLL
-                for (int vv = 0; vv < V; vv++) v.c[vv] = x[e][vv];
-                *reinterpret_cast<vec16<T>*>(out + K * p.out_k + V * j) = v;
+                for (int h = 0; h < H; h++) {
+                    if ((tc.c0 + h * CG + V * j) < p.n_cols) {
+                        vec16<T> v;
+                        FFT_UNROLL
+                        for (int vv = 0; vv < V; vv++) v.c[vv] = x[h][e][vv];
+                        *reinterpret_cast<vec16<T>*>(tc.out + K * p.out_k + h * CG + V * j) = v;
+                    }
+                }
             }
-        }
-    } else {
-        FFT_SYNC();  // last exchange fully consumed
-        FFT_UNROLL
-        for (int e = 0; e < E; e++) {
-            const int K = r + (e << log2TPC);
+        } else {
             FFT_UNROLL
-            for (int vv = 0; vv < V; vv++)
-                *reinterpret_cast<cpx<T>*>(smem + (size_t)(V * j + vv) * pitch + (size_t)K * SZ) = x[e][vv];
-        }
-        FFT_SYNC();
-        const int total = C << log2CPR;
-        for (int g = tid; g < total; g += nthreads) {
-            const int t = g >> log2CPR;
-            const int pos = g & ((1 << log2CPR) - 1);
-            if (c0 + t < p.n_cols)
-                *reinterpret_cast<vec16<T>*>(out + (long long)t * p.out_c + (long long)pos * V) =
-                    *reinterpret_cast<const vec16<T>*>(smem + (size_t)t * pitch + (size_t)pos * 16);
+            for (int h = 0; h < H; h++) {
+                FFT_SYNC_LDS();  // last exchange (or the previous group's image) fully consumed
+                FFT_UNROLL
+                for (int e = 0; e < E; e++) {
+                    const int K = r + (e << log2TPC);
+                    FFT_UNROLL
+                    for (int vv = 0; vv < V; vv++)
+                        *reinterpret_cast<cpx<T>*>(smem + (size_t)(V * j + vv) * pitch + (size_t)K * SZ) = x[h][e][vv];
+                }
+                FFT_SYNC_LDS();
+                FFT_UNROLL
+                for (int i = 0; i < E; i++) {
+                    const int g = tid + i * nthreads;
+                    const int t = h * CG + (g >> log2CPR);
+                    const int pos = g & cpr_mask;
+                    if (tc.c0 + t < p.n_cols)
+                        *reinterpret_cast<vec16<T>*>(tc.out + (long long)t * p.out_c + (long long)pos * V) =
+                            *reinterpret_cast<const vec16<T>*>(smem + (size_t)(g >> log2CPR) * pitch + (size_t)pos * 16);
+                }
+            }
         }
     }
 }

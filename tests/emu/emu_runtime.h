@@ -20,6 +20,8 @@ struct Runtime {
     void h2d(void* dst, const void* src, size_t bytes) { memcpy(dst, src, bytes); }
     int lds_budget = 160 * 1024;
     int max_lds_bytes() { return lds_budget; }
+    int cus = 3;  // few "CUs" so that every workgroup walks several tiles (exercises the persistent loop + prefetch)
+    int num_cus() { return cus; }
     long long launches = 0;
 
     template <class K, class... A>
