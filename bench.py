@@ -43,6 +43,19 @@ WORKLOADS = {
 }
 
 
+def shard_range(rank, world, batch_per_gpu):
+    """Weak scaling by batch index: rank r owns transforms [r*batch, (r+1)*batch) of the world*batch job."""
+    return rank * batch_per_gpu, (rank + 1) * batch_per_gpu
+
+
+def reduce_max_seconds(dist, seconds, device):
+    """The only collective of the benchmark: MAX over ranks of the elapsed time (never on the data path)."""
+    import torch
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
 def make_input(torch, n, batch, dtype, b0, device):
     """Closed-form two-tone complex sinusoids: X_b[f_b] = N, X_b[g_b] = N/2, 0 elsewhere."""
     cdtype = torch.complex64 if dtype == "f32" else torch.complex128
@@ -187,7 +200,8 @@ def main():
     plan.set_stream(stream.cuda_stream)
     info = plan.info()
 
-    x = make_input(torch, n, batch, dtype, rank * batch, device)
+    b_first, b_last = shard_range(rank, world, batch)
+    x = make_input(torch, n, batch, dtype, b_first, device)
     y = x if args.inplace else torch.empty_like(x)
     if args.inplace:
         x_keep = None
@@ -239,9 +253,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = reduce_max_seconds(dist, elapsed, device)
 
     # ---- device-side duration of the same K steps, HIP events on the stream the kernels run on
     ev_ms = plan.timed(x.data_ptr(), y.data_ptr(), args.steps)

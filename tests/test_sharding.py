@@ -1,0 +1,75 @@
+"""N > 1: the batch is sharded by batch index, one process per GPU, no data-path collective.  These CPU tests
+run bench.py's sharding / timing-reduction logic with world_size 2 over gloo (no GPU needed): every rank owns
+`batch` whole transforms, the union covers [0, world*batch) exactly once, and the only communication is the
+barrier + MAX all-reduce of the elapsed time."""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+WORKER = textwrap.dedent('''
+    import os, sys, json
+    import numpy as np
+    import torch, torch.distributed as dist
+    sys.path.insert(0, os.path.join(%r, "tests"))
+    import oracle_lib as O
+    from bench import shard_range, reduce_max_seconds
+    dist.init_process_group(backend="gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    n, per_gpu = 256, 6
+    b0, b1 = shard_range(rank, world, per_gpu)
+    # each rank transforms its own shard with the oracle (the GPU engine's stand-in on this CPU-only box)
+    x = O.gen_two_tone(n, b0, b1 - b0)
+    X = O.oracle_fft(x, -1, "dit")
+    ok = True
+    for i, b in enumerate(range(b0, b1)):
+        f, g = O.two_tone_bins(n, b)
+        ok &= abs(X[i, f] - n) < 1e-9 and abs(X[i, g] - n / 2) < 1e-9
+    owned = torch.zeros(world * per_gpu, dtype=torch.int32)
+    owned[b0:b1] = 1
+    dist.all_reduce(owned)  # test-only bookkeeping: who owns which transform
+    t = reduce_max_seconds(dist, 0.01 * (rank + 1), torch.device("cpu"))
+    if rank == 0:
+        print(json.dumps({"ok": bool(ok), "cover": owned.tolist(), "t": t, "world": world}))
+    dist.barrier()
+    dist.destroy_process_group()
+''')
+
+
+def test_world_size_2_gloo_sharding(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % ROOT)
+    env = dict(os.environ, PYTHONPATH=ROOT, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(free_port()), str(script)],
+                         capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    import json
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    r = json.loads(line)
+    assert r["ok"] and r["world"] == 2
+    assert r["cover"] == [1] * 12  # every transform owned exactly once
+    assert abs(r["t"] - 0.02) < 1e-9  # MAX over ranks
+
+
+def test_shard_range_is_a_partition():
+    sys.path.insert(0, ROOT)
+    from bench import shard_range
+    for world in (1, 2, 4, 8):
+        seen = []
+        for r in range(world):
+            a, b = shard_range(r, world, 512)
+            seen.extend(range(a, b))
+        assert seen == list(range(512 * world))
