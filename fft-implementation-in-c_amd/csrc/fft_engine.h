@@ -10,6 +10,7 @@
 //   void  h2d(void* dst, const void* src, size_t bytes);          // blocking
 //   template <class K, class... A> void launch(K kernel, long long grid, int block, size_t smem, A... args);
 //   int   max_lds_bytes();   int num_cus();
+//   void  mark(int pass_index);   // profiling hook, called after each pass launch (no-op unless enabled)
 //
 // Scheme (reference optimizations/parallel_fft.c:213-272 is the
 // CPU statement of the same four-step idea):
@@ -49,6 +50,8 @@ struct PassDesc {
     long long n_b_per_transform = 1;  // tiles along "b" contributed by ONE transform of the batch
     long long in_b = 0, in_o = 0, in_c = 0, in_l = 0;
     long long out_b = 0, out_o = 0, out_c = 0, out_k = 0;
+    int in_blk_bits = 30;
+    long long in_blk_stride = 0;
     int n_cols = 0;  // valid columns along the tiled dimension; -1: the batch (single-pass row kernel)
     int log2Ntw = 0;
     int nthreads = 0;
@@ -57,10 +60,9 @@ struct PassDesc {
 };
 
 inline int tile_E(long long L) {
-    // elements per thread of a tile kernel: 8 by default (32 data VGPRs + 32 prefetch VGPRs, no spills);
-    // FFT_HIP_E=16 selects the radix-16 variant (fewer LDS exchanges, prefetch only late in the tile)
-    static const int pref = getenv("FFT_HIP_E") ? atoi(getenv("FFT_HIP_E")) : 8;
-    int e = (pref == 16) ? 16 : 8;
+    // elements per thread of a tile kernel: 8 (32 data VGPRs + 2 x 32 prefetch VGPRs fit the 2-waves-per-SIMD
+    // budget without spills; the radix-16 variant needs 64 + 64 and spilled -- see DESIGN.md "what was tried")
+    int e = 8;
     while (e > L) e >>= 1;
     return e;
 }
@@ -261,6 +263,17 @@ class Pow2Plan {
             b.n_cols = 1 << l1;
             if (!choose_tile(b, 1ll << l1, budget)) continue;
             b.n_ct = (1 << l1) >> b.log2C;
+            if (!getenv("FFT_HIP_NO_TILE_MAJOR")) {
+                // Tile-major scratch: pass A stores each tile (L1 rows x C_A columns) as ONE contiguous block, pass B
+                // gathers its rows from the n2/C_A blocks in chunks of C_B*C_A contiguous elements.  The scratch
+                // layout is ours to choose; this turns pass A's strided write into a linear one.
+                const long long CA = 1ll << a.log2C;
+                a.out_k = CA;              // row k1 of the tile
+                a.out_c = 1ll << l1;       // tile base = ct*C_A * L1  (tile_coord multiplies c0 = ct*C_A by out_c)
+                b.in_c = CA;               // row k1 inside a block
+                b.in_blk_bits = a.log2C;   // n2 -> block n2 / C_A, column n2 % C_A
+                b.in_blk_stride = CA << l1;
+            }
             const double cost = seg_cost(a.seg_bytes) + 0.5 + 0.5 * seg_cost(b.seg_bytes) + 0.01 * abs(l1 - l2);
             if (cost < best_cost) {
                 best_cost = cost;
@@ -367,8 +380,7 @@ class Pow2Plan {
         switch (p.E) {
             case 2: launch_one<2, FAM_R2, LM, SM, TW>(tp, grid, p); break;
             case 4: launch_one<4, (FAM == FAM_SR16 ? FAM_R4 : FAM), LM, SM, TW>(tp, grid, p); break;
-            case 8: launch_one<8, FAM, LM, SM, TW>(tp, grid, p); break;
-            default: launch_one<16, FAM, LM, SM, TW>(tp, grid, p); break;
+            default: launch_one<8, FAM, LM, SM, TW>(tp, grid, p); break;
         }
     }
 
@@ -397,6 +409,7 @@ class Pow2Plan {
         tp.n_o = p.n_o;
         tp.in_b = p.in_b; tp.in_o = p.in_o; tp.in_c = p.in_c; tp.in_l = p.in_l;
         tp.out_b = p.out_b; tp.out_o = p.out_o; tp.out_c = p.out_c; tp.out_k = p.out_k;
+        tp.in_blk_bits = p.in_blk_bits; tp.in_blk_stride = p.in_blk_stride;
         tp.inverse = inverse ? 1 : 0;
         tp.scale = scale;
         static const int ablate = getenv("FFT_HIP_ABLATE") ? atoi(getenv("FFT_HIP_ABLATE")) : 0;  // profiling only
@@ -414,6 +427,8 @@ class Pow2Plan {
         const int by_lds = rt->max_lds_bytes() / (p.smem_bytes > 0 ? p.smem_bytes : 1);
         if (per_cu > by_lds) per_cu = by_lds;
         if (per_cu < 1) per_cu = 1;
+        static const int force_per_cu = getenv("FFT_HIP_WG_PER_CU") ? atoi(getenv("FFT_HIP_WG_PER_CU")) : 0;  // experiments
+        if (force_per_cu > 0) per_cu = force_per_cu;
         static const int tiles_per_wg_min = getenv("FFT_HIP_NONPERSISTENT") ? 0 : 1;
         long long grid = (long long)rt->num_cus() * per_cu;
         if (!tiles_per_wg_min || grid > tp.n_tiles) grid = tp.n_tiles;
@@ -450,6 +465,7 @@ class Pow2Plan {
         }
         if (passes.size() == 1) {
             launch_pass(0, in, out, nb, inverse, scale);
+            rt->mark(0);
             return;
         }
         for (int b0 = 0; b0 < nb; b0 += chunk) {
@@ -458,11 +474,16 @@ class Pow2Plan {
             cpx<T>* dst = out + (size_t)b0 * (size_t)n;
             if (passes.size() == 2) {
                 launch_pass(0, src, scratch, cb, inverse, (T)1);
+                rt->mark(0);
                 launch_pass(1, scratch, dst, cb, inverse, scale);
+                rt->mark(1);
             } else {
                 launch_pass(0, src, scratch, cb, inverse, (T)1);
+                rt->mark(0);
                 launch_pass(1, scratch, scratch, cb, inverse, (T)1);
+                rt->mark(1);
                 launch_pass(2, scratch, dst, cb, inverse, scale);
+                rt->mark(2);
             }
         }
     }

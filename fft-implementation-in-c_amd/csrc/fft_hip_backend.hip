@@ -16,6 +16,8 @@
 
 #include <new>
 #include <set>
+#include <utility>
+#include <vector>
 
 #include "../../include/fft_hip.h"
 #include "fft_engine.h"
@@ -53,6 +55,17 @@ struct HipRT {
     void h2d(void* dst, const void* src, size_t bytes) { (void)hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice); }
     int max_lds_bytes() { return lds_limit; }
     int num_cus() { return cus; }
+
+    // per-pass HIP-event profiling (fft_gpu_profile_passes_hip): an event after every pass launch
+    bool profiling = false;
+    std::vector<std::pair<int, hipEvent_t>> marks;
+    void mark(int pass_index) {
+        if (!profiling) return;
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return;
+        (void)hipEventRecord(e, stream);
+        marks.push_back(std::make_pair(pass_index, e));
+    }
 
     template <class K, class... A>
     void launch(K kernel, long long grid, int block, size_t smem, A... args) {
@@ -378,6 +391,35 @@ int fft_gpu_execute_timed_hip(fft_gpu_plan_t p, const void* d_in, void* d_out, i
     HIP_TRY(hipEventSynchronize(p->ev1), return -1);
     HIP_TRY(hipEventElapsedTime(elapsed_ms, p->ev0, p->ev1), return -1);
     return 0;
+}
+
+// One execute with a HIP event after every pass launch: ms[i] = summed device time of pass i's launches,
+// launches[i] = how many launches that was.  Events are recorded on the plan's stream.
+int fft_gpu_profile_passes_hip(fft_gpu_plan_t p, const void* d_in, void* d_out, float* ms, int* launches, int max_passes) {
+    if (!p || !ms || !launches || max_passes <= 0) return -1;
+    DeviceGuard guard(p->device);
+    for (int i = 0; i < max_passes; i++) { ms[i] = 0.f; launches[i] = 0; }
+    hipEvent_t start;
+    HIP_TRY(hipEventCreate(&start), return -1);
+    p->rt.marks.clear();
+    HIP_TRY(hipEventRecord(start, p->rt.stream), return -1);
+    p->rt.profiling = true;
+    int rc = plan_enqueue(p, d_in, d_out);
+    p->rt.profiling = false;
+    HIP_TRY(hipStreamSynchronize(p->rt.stream), rc = -1);
+    hipEvent_t prev = start;
+    for (auto& m : p->rt.marks) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, prev, m.second) == hipSuccess && m.first < max_passes) {
+            ms[m.first] += t;
+            launches[m.first] += 1;
+        }
+        prev = m.second;
+    }
+    for (auto& m : p->rt.marks) (void)hipEventDestroy(m.second);
+    p->rt.marks.clear();
+    (void)hipEventDestroy(start);
+    return rc;
 }
 
 int fft_gpu_plan_info_hip(fft_gpu_plan_t p, fft_gpu_plan_info_t* info) {

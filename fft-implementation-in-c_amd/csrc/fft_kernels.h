@@ -17,6 +17,9 @@
 
 namespace fftk {
 
+#ifndef FFT_WAVES_PER_SIMD
+#define FFT_WAVES_PER_SIMD 2
+#endif
 enum { LOAD_CCONTIG = 0, LOAD_LCONTIG = 1 };
 enum { STORE_CCONTIG = 0, STORE_LCONTIG = 1 };
 enum { FAM_SR16 = 0, FAM_R4 = 1, FAM_R2 = 2 };
@@ -56,6 +59,10 @@ struct TileParams {
     int n_o;
     long long in_b, in_o, in_c, in_l;
     long long out_b, out_o, out_c, out_k;
+    // LOAD_LCONTIG only: the row may be stored as blocks of 2^in_blk_bits elements, block i at i * in_blk_stride
+    // (the tile-major scratch image written by the previous pass); in_blk_bits = 30 means one plain contiguous row
+    int in_blk_bits;
+    long long in_blk_stride;
     long long n_tiles;  // tiles of this launch; a workgroup walks tiles blockIdx, blockIdx + gridDim, ...
     int n_cols;   // columns >= n_cols are padding (read as zero, never stored)
     int inverse;  // 1: inverse transform via the re<->im swap identity
@@ -233,7 +240,7 @@ FFT_DEVICE TileCoord<T> tile_coord(const TileParams<T>& p, long long tile) {
 // FIXED != 0 bakes (log2L << 8 | log2C) into the instantiation: every LDS offset becomes an immediate and the
 // stage loop unrolls (fewer address VGPRs, less integer VALU); FIXED == 0 reads both from the parameters.
 template <typename T, int E, int H, int FAM, int LOADM, int STOREM, bool TWIDDLE, int FIXED>
-FFT_KERNEL void FFT_LAUNCH_BOUNDS2(512, 2) tile_fft_kernel(TileParams<T> p) {
+FFT_KERNEL void FFT_LAUNCH_BOUNDS2(512, FFT_WAVES_PER_SIMD) tile_fft_kernel(TileParams<T> p) {
     constexpr int V = vec16<T>::V;
     constexpr int log2V = Log2<V>::value;
     constexpr int log2E = Log2<E>::value;
@@ -277,8 +284,10 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(512, 2) tile_fft_kernel(TileParams<T> p) {
     //   LOAD_CCONTIG: nxt[h][e] = element l = r + TPC*e of columns h*CG + V*j + (0..V-1)
     //   LOAD_LCONTIG: nxt[h][i] = chunk g = tid + i*nthreads of the group's contiguous rows
     //                 (CG rows * L/V chunks == nthreads * E, so every thread moves exactly E chunks)
-    vec16<T> nxt[H][E];
-    auto prefetch = [&](long long tile) {
+    // DEPTH tiles are kept in flight per workgroup (double-buffered prefetch registers when E <= 8).
+    constexpr int DEPTH = 1;  // 2 was tried (double-buffered prefetch): +32 VGPRs tipped the l-contiguous kernels into spills, 20% slower
+    vec16<T> nxtbuf[DEPTH][H][E];
+    auto prefetch = [&](long long tile, vec16<T> (&nxt)[H][E]) __attribute__((always_inline)) {
         const TileCoord<T> tc = tile_coord(p, tile);
         FFT_UNROLL
         for (int h = 0; h < H; h++) {
@@ -294,7 +303,9 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(512, 2) tile_fft_kernel(TileParams<T> p) {
                     const int g = tid + i * nthreads;
                     const int t = h * CG + (g >> log2CPR);
                     live = (tc.c0 + t) < p.n_cols;
-                    src = tc.in + (long long)t * p.in_c + (long long)(g & cpr_mask) * V;
+                    const int l0 = (g & cpr_mask) * V;
+                    src = tc.in + (long long)t * p.in_c + (long long)(l0 >> p.in_blk_bits) * p.in_blk_stride +
+                          (l0 & ((1 << p.in_blk_bits) - 1));
                 }
                 if (live) {
                     nxt[h][i] = *reinterpret_cast<const vec16<T>*>(src);
@@ -306,11 +317,15 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(512, 2) tile_fft_kernel(TileParams<T> p) {
         }
     };
 
-    long long tile = FFT_BID;
-    if (tile < n_tiles) prefetch(tile);
-    FFT_SYNC();  // tables visible (also drains the first prefetch; steady state uses LDS-only barriers)
+    long long tile0 = FFT_BID;
+    FFT_UNROLL
+    for (int d = 0; d < DEPTH; d++)
+        if (tile0 + d * tile_step < n_tiles) prefetch(tile0 + d * tile_step, nxtbuf[d]);
+    FFT_SYNC();  // tables visible (also drains the first prefetches; steady state uses LDS-only barriers)
 
-    for (; tile < n_tiles; tile += tile_step) {
+    // one tile: consume `nxt` (landed), refill it with the tile DEPTH steps ahead, compute, store
+    auto do_tile = [&](long long tile, vec16<T> (&nxt)[H][E]) __attribute__((always_inline)) {
+        const long long tile_ahead = tile + DEPTH * tile_step;
         const TileCoord<T> tc = tile_coord(p, tile);
         cpx<T> x[H][E][V];
 
@@ -359,22 +374,22 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(512, 2) tile_fft_kernel(TileParams<T> p) {
         // flies during ALL of this tile's stages.  E == 16 (64 + 64 VGPRs would spill under the 2-waves-per-SIMD
         // budget): issued from inside the last group's stages, at the point where the data registers are dead.
         constexpr bool EARLY = (E <= 8);
-        const bool have_next = (tile + tile_step) < n_tiles;
-        if (EARLY && have_next) prefetch(tile + tile_step);
+        const bool have_next = tile_ahead < n_tiles;
+        if (EARLY && have_next) prefetch(tile_ahead, nxt);
         if (!(p.ablate & 2)) {
             FFT_UNROLL
             for (int h = 0; h < H; h++) {
                 FFT_SYNC_LDS();  // staging image / previous group's last exchange / previous tile fully consumed
                 if (h == H - 1) {
                     stockham_all_stages<T, E, FAM, V>(x[h], smem, tw, r, j, log2J, log2TPC, log2L, [&]() {
-                        if (!EARLY && have_next) prefetch(tile + tile_step);
+                        if (!EARLY && have_next) prefetch(tile_ahead, nxt);
                     });
                 } else {
                     stockham_all_stages<T, E, FAM, V>(x[h], smem, tw, r, j, log2J, log2TPC, log2L, []() {});
                 }
             }
         } else if (!EARLY && have_next) {
-            prefetch(tile + tile_step);
+            prefetch(tile_ahead, nxt);
         }
 
         // ---- the prefetched tile has landed long ago: take the vmcnt wait now, before this tile's stores
@@ -475,6 +490,12 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(512, 2) tile_fft_kernel(TileParams<T> p) {
                 }
             }
         }
+    };
+
+    for (long long tile = tile0; tile < n_tiles; tile += DEPTH * tile_step) {
+        FFT_UNROLL
+        for (int d = 0; d < DEPTH; d++)
+            if (tile + d * tile_step < n_tiles) do_tile(tile + d * tile_step, nxtbuf[d]);
     }
 }
 

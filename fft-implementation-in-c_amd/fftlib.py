@@ -58,6 +58,7 @@ SIGNATURES = {
     "fft_gpu_execute_ptr_hip": (_i, [_vp, _vp, _vp]), "fft_gpu_plan_sync_hip": (_i, [_vp]),
     "fft_gpu_execute_timed_hip": (_i, [_vp, _vp, _vp, _i, C.POINTER(C.c_float)]),
     "fft_gpu_dft_1d_batch_hip": (_i, [_vp, _vp, _i, _i, _i, _i]),
+    "fft_gpu_profile_passes_hip": (_i, [_vp, _vp, _vp, C.POINTER(C.c_float), C.POINTER(C.c_int), _i]),
     "fft_gpu_bit_reverse_hip": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     # include/fft_hip.h part 2 (additive, public)
     "fft_gpu_device_count": (_i, []), "fft_gpu_alloc_f32": (_vp, [_sz]),
@@ -183,6 +184,13 @@ class Plan:
         if self.lib.fft_gpu_execute_timed(self.handle, d_in, d_out, iters, C.byref(ms)) != 0:
             raise RuntimeError("fft_gpu_execute_timed failed")
         return ms.value
+
+    def profile_passes(self, d_in, d_out, max_passes=4):
+        ms = (C.c_float * max_passes)()
+        cnt = (C.c_int * max_passes)()
+        if self.lib.fft_gpu_profile_passes_hip(self.handle, d_in, d_out, ms, cnt, max_passes) != 0:
+            raise RuntimeError("fft_gpu_profile_passes_hip failed")
+        return [(ms[i], cnt[i]) for i in range(max_passes) if cnt[i]]
 
     def set_stream(self, stream_ptr):
         self.lib.fft_gpu_plan_set_stream(self.handle, stream_ptr)

@@ -97,6 +97,8 @@ int fft_gpu_execute_ptr_hip(fft_gpu_plan_t plan, const void* d_in, void* d_out);
 int fft_gpu_plan_sync_hip(fft_gpu_plan_t plan);
 /* `iters` back-to-back executes bracketed by hipEvents recorded on the plan's stream */
 int fft_gpu_execute_timed_hip(fft_gpu_plan_t plan, const void* d_in, void* d_out, int iters, float* elapsed_ms);
+/* one execute with a HIP event after every pass launch: per-pass device milliseconds and launch counts */
+int fft_gpu_profile_passes_hip(fft_gpu_plan_t plan, const void* d_in, void* d_out, float* ms, int* launches, int max_passes);
 int fft_gpu_dft_1d_batch_hip(const void* in, void* out, int n, int batch, fft_direction dir, fft_precision_t prec);
 /* out[b][bit_reverse(i)] = in[b][i]; in == out allowed (reference: the swap loop radix2_dit.c:70-77) */
 int fft_gpu_bit_reverse_hip(const void* d_in, void* d_out, int n, int batch, fft_precision_t prec, void* hip_stream);

@@ -22,6 +22,7 @@ struct Runtime {
     int max_lds_bytes() { return lds_budget; }
     int cus = 3;  // few "CUs" so that every workgroup walks several tiles (exercises the persistent loop + prefetch)
     int num_cus() { return cus; }
+    void mark(int) {}
     long long launches = 0;
 
     template <class K, class... A>
