@@ -193,11 +193,20 @@ class Pow2Plan {
         return true;
     }
 
-    static double seg_cost(int seg_bytes) {
-        if (seg_bytes >= 128) return 1.0;
-        if (seg_bytes >= 64) return 1.35;
-        if (seg_bytes >= 32) return 2.2;
+    // Relative time of a pass vs a pass with >= 512-byte row segments, measured on MI355X:
+    // strided READS of narrow segments cost more than strided writes; 32-byte stores are ruinous.
+    static double seg_cost(int seg_bytes) {  // column pass: strided read + strided (or tile-major) write
+        if (seg_bytes >= 512) return 1.0;
+        if (seg_bytes >= 256) return 1.07;
+        if (seg_bytes >= 128) return 1.27;
+        if (seg_bytes >= 64) return 1.57;
+        if (seg_bytes >= 32) return 2.1;
         return 4.0;
+    }
+    static double store_cost(int seg_bytes) {  // row pass: contiguous read, strided store
+        if (seg_bytes >= 64) return 1.0;
+        if (seg_bytes >= 32) return 4.3;
+        return 8.0;
     }
 
     bool build(RT* runtime, int log2n_, int algo_, int batch) {
@@ -274,7 +283,7 @@ class Pow2Plan {
                 b.in_blk_bits = a.log2C;   // n2 -> block n2 / C_A, column n2 % C_A
                 b.in_blk_stride = CA << l1;
             }
-            const double cost = seg_cost(a.seg_bytes) + 0.5 + 0.5 * seg_cost(b.seg_bytes) + 0.01 * abs(l1 - l2);
+            const double cost = seg_cost(a.seg_bytes) + 0.5 + 0.5 * store_cost(b.seg_bytes) + 0.01 * abs(l1 - l2);
             if (cost < best_cost) {
                 best_cost = cost;
                 best.clear();
@@ -309,7 +318,7 @@ class Pow2Plan {
                     b.n_cols = 1 << l1;
                     if (!choose_tile(b, 1ll << l1, budget)) continue;
                     b.n_ct = (1 << l1) >> b.log2C;
-                    const double cost = seg_cost(a.seg_bytes) + seg_cost(m.seg_bytes) + 0.5 + 0.5 * seg_cost(b.seg_bytes) +
+                    const double cost = seg_cost(a.seg_bytes) + seg_cost(m.seg_bytes) + 0.5 + 0.5 * store_cost(b.seg_bytes) +
                                         0.01 * (abs(l1 - l2) + abs(l2 - l3));
                     if (cost < best_cost) {
                         best_cost = cost;
@@ -414,6 +423,8 @@ class Pow2Plan {
         tp.scale = scale;
         static const int ablate = getenv("FFT_HIP_ABLATE") ? atoi(getenv("FFT_HIP_ABLATE")) : 0;  // profiling only
         tp.ablate = ablate;
+        static const int pair16 = getenv("FFT_HIP_PAIR16") ? atoi(getenv("FFT_HIP_PAIR16")) : 0;
+        tp.pair16 = (pair16 && ((1ll << p.log2C) * SZ < 128)) ? 1 : 0;
         if (p.n_cols < 0) {  // single-pass row kernel: columns are the transforms of the batch
             tp.n_cols = nb;
             tp.n_ct = (int)((nb + (1ll << p.log2C) - 1) >> p.log2C);
@@ -548,16 +559,18 @@ class BluesteinPlan {
 
     void execute(const cpx<T>* in, cpx<T>* out, int nb) {
         const long long m = 1ll << log2m;
-        const long long tot_m = (long long)nb * m, tot_n = (long long)nb * n;
-        rt->launch(fftk::blu_modulate_kernel<T>, Pow2Plan<T, RT>::grid_for(tot_m, 256), 256, (size_t)0, in,
-                   (const cpx<T>*)chirp, work, n, log2m, tot_m);
+        const unsigned per_block = 256 * BLU_PER_THREAD;
+        const unsigned bpr_m = (unsigned)((m + per_block - 1) / per_block);
+        const unsigned bpr_n = (unsigned)(((long long)n + per_block - 1) / per_block);
+        rt->launch(fftk::blu_modulate_kernel<T>, (long long)bpr_m * nb, 256, (size_t)0, in, (const cpx<T>*)chirp, work, n,
+                   log2m, bpr_m);
         core.execute(work, work, nb, false);
-        rt->launch(fftk::blu_pointwise_kernel<T>, Pow2Plan<T, RT>::grid_for(tot_m, 256), 256, (size_t)0, work,
-                   (const cpx<T>*)bfft, log2m, tot_m);
+        rt->launch(fftk::blu_pointwise_kernel<T>, (long long)bpr_m * nb, 256, (size_t)0, work, (const cpx<T>*)bfft, log2m,
+                   bpr_m);
         core.execute(work, work, nb, true);  // carries the 1/m
         const T scale = dir > 0 ? (T)(1.0L / (long double)n) : (T)1;
-        rt->launch(fftk::blu_demodulate_kernel<T>, Pow2Plan<T, RT>::grid_for(tot_n, 256), 256, (size_t)0,
-                   (const cpx<T>*)work, (const cpx<T>*)chirp, out, n, log2m, tot_n, scale);
+        rt->launch(fftk::blu_demodulate_kernel<T>, (long long)bpr_n * nb, 256, (size_t)0, (const cpx<T>*)work,
+                   (const cpx<T>*)chirp, out, n, log2m, bpr_n, scale);
     }
 };
 

@@ -66,6 +66,7 @@ struct TileParams {
     long long n_tiles;  // tiles of this launch; a workgroup walks tiles blockIdx, blockIdx + gridDim, ...
     int n_cols;   // columns >= n_cols are padding (read as zero, never stored)
     int inverse;  // 1: inverse transform via the re<->im swap identity
+    int pair16;   // tile order: pair half-line neighbours on one XCD (see tile_coord)
     int ablate;   // profiling only (FFT_HIP_ABLATE): 1 skip inter-pass twiddle, 2 skip stages
     T scale;      // applied at the store (1/N folded into the last pass)
 };
@@ -226,7 +227,14 @@ struct TileCoord {
 template <typename T>
 FFT_DEVICE TileCoord<T> tile_coord(const TileParams<T>& p, long long tile) {
     TileCoord<T> tc;
-    const unsigned t32 = (unsigned)tile;  // launches never exceed 2^31 tiles
+    unsigned t32 = (unsigned)tile;  // launches never exceed 2^31 tiles
+    if (p.pair16 && tile < (p.n_tiles & ~15ll)) {
+        // Within every 16 consecutive sequence numbers, workgroups g and g + 8 (same XCD under the observed
+        // round-robin placement; speed only, never correctness) get column tiles 2k and 2k + 1, i.e. the two
+        // halves of the same 128-byte lines, in the same iteration, so that XCD's L2 sees both halves together.
+        const unsigned b = t32 & 15u;
+        t32 = (t32 & ~15u) | (((b & 7u) << 1) | (b >> 3));
+    }
     const unsigned ct = t32 % (unsigned)p.n_ct;
     const unsigned rest = t32 / (unsigned)p.n_ct;
     const unsigned o = rest % (unsigned)p.n_o;
@@ -564,36 +572,57 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS(256) scale_copy_kernel(const cpx<T>* in, cpx<T
 //   pointwise:   a[b][k] *= B[k],  B = FFT_m(b), b[k] = b[m-k] = chirp[k]        (:116-130)
 //   demodulate:  y[b][k] = a[b][k] * conj(chirp[k]) * scale                      (:139-148)
 // ---------------------------------------------------------------------------
+// One workgroup handles 256 * BLU_PER_THREAD consecutive k of ONE transform: block -> (row, k-block) costs a
+// single scalar 32-bit division per workgroup, no per-element 64-bit division.
+#define BLU_PER_THREAD 4
+
 template <typename T>
 FFT_KERNEL void FFT_LAUNCH_BOUNDS(256)
-    blu_modulate_kernel(const cpx<T>* x, const cpx<T>* chirp, cpx<T>* a, int n, int log2m, long long total) {
-    const long long stride = FFT_NBLOCKS * FFT_NTHREADS;
-    const long long mmask = (1ll << log2m) - 1;
-    for (long long i = FFT_BID * FFT_NTHREADS + FFT_TID; i < total; i += stride) {
-        const long long b = i >> log2m;
-        const int k = (int)(i & mmask);
-        cpx<T> v = mk<T>((T)0, (T)0);
-        if (k < n) v = cmul_conj(x[b * n + k], chirp[k]);
-        a[i] = v;
+    blu_modulate_kernel(const cpx<T>* x, const cpx<T>* chirp, cpx<T>* a, int n, int log2m, unsigned blocks_per_row) {
+    const unsigned bid = (unsigned)FFT_BID;
+    const unsigned row = bid / blocks_per_row;
+    const int k0 = (int)(bid - row * blocks_per_row) * (256 * BLU_PER_THREAD) + FFT_TID;
+    const cpx<T>* xr = x + (long long)row * n;
+    cpx<T>* ar = a + ((long long)row << log2m);
+    const int m = 1 << log2m;
+    FFT_UNROLL
+    for (int u = 0; u < BLU_PER_THREAD; u++) {
+        const int k = k0 + u * 256;
+        if (k < m) {
+            cpx<T> v = mk<T>((T)0, (T)0);
+            if (k < n) v = cmul_conj(xr[k], chirp[k]);
+            ar[k] = v;
+        }
     }
 }
 
 template <typename T>
 FFT_KERNEL void FFT_LAUNCH_BOUNDS(256)
-    blu_pointwise_kernel(cpx<T>* a, const cpx<T>* bfft, int log2m, long long total) {
-    const long long stride = FFT_NBLOCKS * FFT_NTHREADS;
-    const long long mmask = (1ll << log2m) - 1;
-    for (long long i = FFT_BID * FFT_NTHREADS + FFT_TID; i < total; i += stride) a[i] = cmul(a[i], bfft[i & mmask]);
+    blu_pointwise_kernel(cpx<T>* a, const cpx<T>* bfft, int log2m, unsigned blocks_per_row) {
+    const unsigned bid = (unsigned)FFT_BID;
+    const unsigned row = bid / blocks_per_row;
+    const int k0 = (int)(bid - row * blocks_per_row) * (256 * BLU_PER_THREAD) + FFT_TID;
+    cpx<T>* ar = a + ((long long)row << log2m);
+    const int m = 1 << log2m;
+    FFT_UNROLL
+    for (int u = 0; u < BLU_PER_THREAD; u++) {
+        const int k = k0 + u * 256;
+        if (k < m) ar[k] = cmul(ar[k], bfft[k]);
+    }
 }
 
 template <typename T>
 FFT_KERNEL void FFT_LAUNCH_BOUNDS(256) blu_demodulate_kernel(const cpx<T>* a, const cpx<T>* chirp, cpx<T>* y, int n,
-                                                             int log2m, long long total /* batch*n */, T scale) {
-    const long long stride = FFT_NBLOCKS * FFT_NTHREADS;
-    for (long long i = FFT_BID * FFT_NTHREADS + FFT_TID; i < total; i += stride) {
-        const long long b = i / n;
-        const int k = (int)(i - b * n);
-        y[i] = cscale(cmul_conj(a[(b << log2m) + k], chirp[k]), scale);
+                                                             int log2m, unsigned blocks_per_row, T scale) {
+    const unsigned bid = (unsigned)FFT_BID;
+    const unsigned row = bid / blocks_per_row;
+    const int k0 = (int)(bid - row * blocks_per_row) * (256 * BLU_PER_THREAD) + FFT_TID;
+    const cpx<T>* ar = a + ((long long)row << log2m);
+    cpx<T>* yr = y + (long long)row * n;
+    FFT_UNROLL
+    for (int u = 0; u < BLU_PER_THREAD; u++) {
+        const int k = k0 + u * 256;
+        if (k < n) yr[k] = cscale(cmul_conj(ar[k], chirp[k]), scale);
     }
 }
 
