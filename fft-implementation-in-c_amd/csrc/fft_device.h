@@ -32,6 +32,19 @@ unsigned shfl_xor_u32(unsigned v, int mask);
 #define FFT_SYNC() emu::sync_threads()
 #define FFT_SYNC_LDS() emu::sync_threads()
 #define FFT_WAIT_LOADED(v) (void)(v)
+namespace emu {
+template <typename T>
+inline T shfl_xor_any(T v, int mask) {
+    static_assert(sizeof(T) % 4 == 0, "32-bit granules");
+    unsigned w[sizeof(T) / 4];
+    memcpy(w, &v, sizeof(T));
+    for (unsigned i = 0; i < sizeof(T) / 4; i++) w[i] = shfl_xor_u32(w[i], mask);
+    memcpy(&v, w, sizeof(T));
+    return v;
+}
+}  // namespace emu
+#define FFT_SHFL_XOR(v, mask) emu::shfl_xor_any(v, mask)
+#define FFT_OPAQUE(v) (void)(v)
 #define FFT_LAUNCH_BOUNDS(n)
 #define FFT_LAUNCH_BOUNDS2(n, w)
 #define FFT_RESTRICT
@@ -54,6 +67,14 @@ unsigned shfl_xor_u32(unsigned v, int mask);
 // an in-order counter shared by loads and stores, so waiting for the prefetched tile BEFORE this tile's
 // stores are issued keeps the store latency out of the next iteration's critical path.
 #define FFT_WAIT_LOADED(v) asm volatile("" ::"v"(v))
+#define FFT_SHFL_XOR(v, mask) __shfl_xor(v, mask, 64)
+// Hide a loop-invariant value from the optimizer: without this, LICM hoists every per-stage LDS address and
+// twiddle index out of the persistent tile loop and keeps hundreds of them live in VGPRs across it.
+#ifdef FFT_NO_OPAQUE
+#define FFT_OPAQUE(v) (void)(v)
+#else
+#define FFT_OPAQUE(v) asm volatile("" : "+v"(v))
+#endif
 #define FFT_LAUNCH_BOUNDS(n) __launch_bounds__(n)
 #define FFT_LAUNCH_BOUNDS2(n, w) __launch_bounds__(n, w)
 #define FFT_RESTRICT __restrict__

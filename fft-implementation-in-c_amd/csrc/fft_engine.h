@@ -10,6 +10,7 @@
 //   void  h2d(void* dst, const void* src, size_t bytes);          // blocking
 //   template <class K, class... A> void launch(K kernel, long long grid, int block, size_t smem, A... args);
 //   int   max_lds_bytes();   int num_cus();
+//   template <class K> int max_blocks_per_cu(K kernel, int threads, size_t smem);
 //   void  mark(int pass_index);   // profiling hook, called after each pass launch (no-op unless enabled)
 //
 // Scheme (reference optimizations/parallel_fft.c:213-272 is the
@@ -37,12 +38,13 @@ namespace ffteng {
 
 using fftk::cpx;
 
-enum Algo { ALGO_AUTO = 0, ALGO_RADIX2 = 1, ALGO_RADIX4 = 2, ALGO_SPLIT_RADIX = 3, ALGO_RADIX2_GLOBAL = 4 };
+enum Algo { ALGO_AUTO = 0, ALGO_RADIX2 = 1, ALGO_RADIX4 = 2, ALGO_SPLIT_RADIX = 3, ALGO_RADIX2_GLOBAL = 4, ALGO_BLUESTEIN = 5, ALGO_RADIX2_SHFL = 6 };
 
 struct PassDesc {
     int log2L = 0, log2C = 0, E = 16;
     int log2H = 0;  // column groups per tile (kernel template H = 1 << log2H)
     int tw_levels = 2;  // inter-pass twiddle: 2- or 3-level table product
+    int fam = 0;        // butterfly family of this pass (fftk::FAM_*)
     int sa_bits = 0, t0_bits = 0, t1_bits = 0, t2_bits = 0;
     int o_sb = 0, o_t0 = 0, o_t1 = 0, o_t2 = 0, tables_elems = 0, off_tables = 0;
     int loadm = 0, storem = 0, twiddle = 0;
@@ -59,10 +61,18 @@ struct PassDesc {
     int seg_bytes = 0;  // contiguous bytes per row segment on the c-contiguous side
 };
 
-inline int tile_E(long long L) {
+inline int tile_E(long long L, int kind = 0);
+inline int tile_E(long long L, int kind) {  // kind: 0 single-pass rows, 1 column pass, 2 row pass with transposed store
     // elements per thread of a tile kernel: 8 (32 data VGPRs + 2 x 32 prefetch VGPRs fit the 2-waves-per-SIMD
     // budget without spills; the radix-16 variant needs 64 + 64 and spilled -- see DESIGN.md "what was tried")
-    int e = 8;
+    static int pref[3] = {0, 0, 0};
+    static bool init = false;
+    if (!init) {
+        init = true;
+        pref[0] = 8; pref[1] = 8; pref[2] = 8;
+        if (const char* e = getenv("FFT_HIP_E")) sscanf(e, "%d,%d,%d", &pref[0], &pref[1], &pref[2]);
+    }
+    int e = (pref[kind] == 16) ? 16 : 8;
     while (e > L) e >>= 1;
     return e;
 }
@@ -214,9 +224,10 @@ class Pow2Plan {
         log2n = log2n_;
         max_batch = batch;
         algo = algo_ == ALGO_AUTO ? ALGO_SPLIT_RADIX : algo_;
+        if (algo == ALGO_RADIX2_SHFL && (log2n < 7 || log2n > 10)) algo = ALGO_RADIX2;  // one-wave kernel covers 128..1024
         fam = algo == ALGO_RADIX2 ? fftk::FAM_R2 : algo == ALGO_RADIX4 ? fftk::FAM_R4 : fftk::FAM_SR16;
         const long long n = 1ll << log2n;
-        if (algo == ALGO_RADIX2_GLOBAL) {
+        if (algo == ALGO_RADIX2_GLOBAL || algo == ALGO_RADIX2_SHFL) {
             if (log2n >= 1) {
                 std::vector<cpx<T>> t;
                 make_twiddle_table<T>(t, n, n / 2, 1);
@@ -262,12 +273,12 @@ class Pow2Plan {
             const int l2 = log2n - l1;
             if (n_force >= 1 && !(n_force == 2 && force[0] == l1)) continue;
             PassDesc a, b;
-            a.log2L = l1; a.E = tile_E(1ll << l1); a.loadm = fftk::LOAD_CCONTIG; a.storem = fftk::STORE_CCONTIG; a.twiddle = 1; a.log2Ntw = log2n;
+            a.log2L = l1; a.E = tile_E(1ll << l1, 1); a.loadm = fftk::LOAD_CCONTIG; a.storem = fftk::STORE_CCONTIG; a.twiddle = 1; a.log2Ntw = log2n;
             a.in_b = n; a.in_c = 1; a.in_l = 1ll << l2; a.out_b = n; a.out_c = 1; a.out_k = 1ll << l2;
             a.n_cols = 1 << l2;
             if (!choose_tile(a, 1ll << l2, budget)) continue;
             a.n_ct = (1 << l2) >> a.log2C;
-            b.log2L = l2; b.E = tile_E(1ll << l2); b.loadm = fftk::LOAD_LCONTIG; b.storem = fftk::STORE_CCONTIG;
+            b.log2L = l2; b.E = tile_E(1ll << l2, 2); b.loadm = fftk::LOAD_LCONTIG; b.storem = fftk::STORE_CCONTIG;
             b.in_b = n; b.in_c = 1ll << l2; b.in_l = 1; b.out_b = n; b.out_c = 1; b.out_k = 1ll << l1;
             b.n_cols = 1 << l1;
             if (!choose_tile(b, 1ll << l1, budget)) continue;
@@ -300,18 +311,18 @@ class Pow2Plan {
                     if (n_force >= 1 && !(n_force == 3 && force[0] == l1 && force[1] == l2)) continue;
                     const long long M = 1ll << (l2 + l3);
                     PassDesc a, m, b;
-                    a.log2L = l1; a.E = tile_E(1ll << l1); a.loadm = fftk::LOAD_CCONTIG; a.storem = fftk::STORE_CCONTIG; a.twiddle = 1; a.log2Ntw = log2n;
+                    a.log2L = l1; a.E = tile_E(1ll << l1, 1); a.loadm = fftk::LOAD_CCONTIG; a.storem = fftk::STORE_CCONTIG; a.twiddle = 1; a.log2Ntw = log2n;
                     a.in_b = n; a.in_c = 1; a.in_l = M; a.out_b = n; a.out_c = 1; a.out_k = M;
                     a.n_cols = (int)M;
                     if (!choose_tile(a, M, budget)) continue;
                     a.n_ct = (int)(M >> a.log2C);
-                    m.log2L = l2; m.E = tile_E(1ll << l2); m.loadm = fftk::LOAD_CCONTIG; m.storem = fftk::STORE_CCONTIG; m.twiddle = 1; m.log2Ntw = l2 + l3;
+                    m.log2L = l2; m.E = tile_E(1ll << l2, 1); m.loadm = fftk::LOAD_CCONTIG; m.storem = fftk::STORE_CCONTIG; m.twiddle = 1; m.log2Ntw = l2 + l3;
                     m.n_b_per_transform = 1ll << l1;
                     m.in_b = M; m.in_c = 1; m.in_l = 1ll << l3; m.out_b = M; m.out_c = 1; m.out_k = 1ll << l3;
                     m.n_cols = 1 << l3;
                     if (!choose_tile(m, 1ll << l3, budget)) continue;
                     m.n_ct = (1 << l3) >> m.log2C;
-                    b.log2L = l3; b.E = tile_E(1ll << l3); b.loadm = fftk::LOAD_LCONTIG; b.storem = fftk::STORE_CCONTIG;
+                    b.log2L = l3; b.E = tile_E(1ll << l3, 2); b.loadm = fftk::LOAD_LCONTIG; b.storem = fftk::STORE_CCONTIG;
                     b.n_o = 1 << l2;
                     b.in_b = n; b.in_o = 1ll << l3; b.in_c = M; b.in_l = 1;
                     b.out_b = n; b.out_o = 1ll << l1; b.out_c = 1; b.out_k = 1ll << (l1 + l2);
@@ -331,6 +342,19 @@ class Pow2Plan {
         }
         if (best.empty()) return false;
         passes = best;
+        // Butterfly family per pass.  An explicit algo applies to every pass.  AUTO picks what measured fastest on
+        // MI355X per pass shape: rows-in/rows-out and column passes run radix-4 stages, the
+        // row pass with transposed store runs radix-8 (split-radix codelet) stages.
+        {
+            int auto_fams[3] = {fftk::FAM_R4, fftk::FAM_R4, fftk::FAM_SR16};  // single-pass, column pass, row pass
+            if (const char* e = getenv("FFT_HIP_AUTO_FAMS")) sscanf(e, "%d,%d,%d", &auto_fams[0], &auto_fams[1], &auto_fams[2]);
+            for (auto& p : passes) {
+                if (algo_ != ALGO_AUTO) p.fam = fam;
+                else if (p.loadm == fftk::LOAD_CCONTIG) p.fam = auto_fams[1];
+                else if (p.storem == fftk::STORE_CCONTIG) p.fam = auto_fams[2];
+                else p.fam = auto_fams[0];
+            }
+        }
 
         // ---- tables: one blob per pass, laid out exactly as the kernel keeps it in LDS
         for (auto& p : passes) {
@@ -380,7 +404,17 @@ class Pow2Plan {
 
     template <int E, int FAM, int LM, int SM, bool TW>
     void launch_one(const fftk::TileParams<T>& tp, long long grid, const PassDesc& p) {
-        rt->launch(fftk::tile_fft_kernel<T, E, 1, FAM, LM, SM, TW, 0>, grid, p.nthreads, (size_t)p.smem_bytes, tp);
+        auto kernel = fftk::tile_fft_kernel<T, E, 1, FAM, LM, SM, TW, 0>;
+        if (grid < 0) {
+            // persistent grid: exactly the workgroups that are resident at once (occupancy query: VGPRs, LDS, waves)
+            int per_cu = rt->max_blocks_per_cu(kernel, p.nthreads, (size_t)p.smem_bytes);
+            static const int force_per_cu = getenv("FFT_HIP_WG_PER_CU") ? atoi(getenv("FFT_HIP_WG_PER_CU")) : 0;  // experiments
+            if (force_per_cu > 0) per_cu = force_per_cu;
+            if (per_cu < 1) per_cu = 1;
+            grid = (long long)rt->num_cus() * per_cu;
+            if (grid > tp.n_tiles) grid = tp.n_tiles;
+        }
+        rt->launch(kernel, grid, p.nthreads, (size_t)p.smem_bytes, tp);
     }
 
     template <int FAM, int LM, int SM, bool TW>
@@ -389,7 +423,8 @@ class Pow2Plan {
         switch (p.E) {
             case 2: launch_one<2, FAM_R2, LM, SM, TW>(tp, grid, p); break;
             case 4: launch_one<4, (FAM == FAM_SR16 ? FAM_R4 : FAM), LM, SM, TW>(tp, grid, p); break;
-            default: launch_one<8, FAM, LM, SM, TW>(tp, grid, p); break;
+            case 8: launch_one<8, FAM, LM, SM, TW>(tp, grid, p); break;
+            default: launch_one<16, (FAM == FAM_SR16 ? FAM_R4 : FAM), LM, SM, TW>(tp, grid, p); break;  // E = 16: radix-4 / radix-2 only
         }
     }
 
@@ -433,17 +468,9 @@ class Pow2Plan {
             tp.n_cols = p.n_cols;
             tp.n_tiles = (long long)nb * p.n_b_per_transform * p.n_o * p.n_ct;
         }
-        // persistent grid: as many workgroups as stay resident (8 waves per CU), each walks n_tiles / grid tiles
-        int per_cu = 512 / p.nthreads;
-        const int by_lds = rt->max_lds_bytes() / (p.smem_bytes > 0 ? p.smem_bytes : 1);
-        if (per_cu > by_lds) per_cu = by_lds;
-        if (per_cu < 1) per_cu = 1;
-        static const int force_per_cu = getenv("FFT_HIP_WG_PER_CU") ? atoi(getenv("FFT_HIP_WG_PER_CU")) : 0;  // experiments
-        if (force_per_cu > 0) per_cu = force_per_cu;
-        static const int tiles_per_wg_min = getenv("FFT_HIP_NONPERSISTENT") ? 0 : 1;
-        long long grid = (long long)rt->num_cus() * per_cu;
-        if (!tiles_per_wg_min || grid > tp.n_tiles) grid = tp.n_tiles;
-        switch (fam) {
+        static const int nonpersistent = getenv("FFT_HIP_NONPERSISTENT") ? 1 : 0;
+        long long grid = nonpersistent ? tp.n_tiles : -1;  // -1: launch_one sizes the persistent grid from the occupancy query
+        switch (p.fam) {
             case fftk::FAM_R2: launch_fam<fftk::FAM_R2, 1>(tp, grid, p); break;
             case fftk::FAM_R4: launch_fam<fftk::FAM_R4, 1>(tp, grid, p); break;
             default: launch_fam<fftk::FAM_SR16, 1>(tp, grid, p); break;
@@ -464,6 +491,19 @@ class Pow2Plan {
         if (log2n == 0) {
             if (in != out || scale != (T)1)
                 rt->launch(fftk::scale_copy_kernel<T>, grid_for(nb, 256), 256, (size_t)0, in, out, (long long)nb, scale);
+            return;
+        }
+        if (algo == ALGO_RADIX2_SHFL) {
+            long long grid = ((long long)nb + 3) / 4;
+            if (grid > (long long)rt->num_cus() * 8) grid = (long long)rt->num_cus() * 8;
+            const size_t smem = (size_t)(n / 2 + 4 * n) * SZ;
+            const int inv = inverse ? 1 : 0;
+            switch (log2n) {
+                case 7: rt->launch(fftk::wave_dit_kernel<T, 2>, grid, 256, smem, in, out, (const cpx<T>*)tw_half, (long long)nb, inv, scale); break;
+                case 8: rt->launch(fftk::wave_dit_kernel<T, 4>, grid, 256, smem, in, out, (const cpx<T>*)tw_half, (long long)nb, inv, scale); break;
+                case 9: rt->launch(fftk::wave_dit_kernel<T, 8>, grid, 256, smem, in, out, (const cpx<T>*)tw_half, (long long)nb, inv, scale); break;
+                default: rt->launch(fftk::wave_dit_kernel<T, 16>, grid, 256, smem, in, out, (const cpx<T>*)tw_half, (long long)nb, inv, scale); break;
+            }
             return;
         }
         if (algo == ALGO_RADIX2_GLOBAL) {

@@ -14,6 +14,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <map>
 #include <new>
 #include <set>
 #include <utility>
@@ -55,6 +56,26 @@ struct HipRT {
     void h2d(void* dst, const void* src, size_t bytes) { (void)hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice); }
     int max_lds_bytes() { return lds_limit; }
     int num_cus() { return cus; }
+    std::map<const void*, int> occ_cache;
+    template <class K>
+    int max_blocks_per_cu(K kernel, int threads, size_t smem) {
+        const void* key = reinterpret_cast<const void*>(kernel);
+        auto it = occ_cache.find(key);
+        if (it != occ_cache.end()) return it->second;
+        if (smem > 48 * 1024 && !configured.count(key)) {
+            (void)hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, lds_limit);
+            (void)hipGetLastError();
+            configured.insert(key);
+        }
+        int n = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, key, threads, smem) != hipSuccess || n < 1) {
+            (void)hipGetLastError();
+            n = 1;
+        }
+        if (n > 8) n = 8;
+        occ_cache[key] = n;
+        return n;
+    }
 
     // per-pass HIP-event profiling (fft_gpu_profile_passes_hip): an event after every pass launch
     bool profiling = false;
@@ -275,7 +296,7 @@ fft_gpu_plan_t fft_gpu_plan_1d_ex_hip(int n, int batch, fft_direction dir, fft_p
         fprintf(stderr, "fft_hip: plan requested before fft_gpu_init\n");
         return NULL;
     }
-    if (n <= 0 || batch <= 0 || (prec != FFT_PREC_F32 && prec != FFT_PREC_F64) || (int)algo < 0 || (int)algo > 5) {
+    if (n <= 0 || batch <= 0 || (prec != FFT_PREC_F32 && prec != FFT_PREC_F64) || (int)algo < 0 || (int)algo > 6) {
         fprintf(stderr, "fft_hip: invalid plan arguments (n=%d batch=%d prec=%d algo=%d)\n", n, batch, (int)prec, (int)algo);
         return NULL;
     }
@@ -434,7 +455,10 @@ int fft_gpu_plan_info_hip(fft_gpu_plan_t p, fft_gpu_plan_info_t* info) {
         info->algo = core->algo;
         info->chunk_batch = core->chunk;
         info->workspace_bytes += core->scratch_bytes;
-        if (core->algo == ffteng::ALGO_RADIX2_GLOBAL) {
+        if (core->algo == ffteng::ALGO_RADIX2_SHFL) {
+            info->n_passes = 1;
+            info->factors[0] = 1 << core->log2n;
+        } else if (core->algo == ffteng::ALGO_RADIX2_GLOBAL) {
             info->n_passes = core->log2n + 1;
         } else {
             info->n_passes = (int)core->passes.size();

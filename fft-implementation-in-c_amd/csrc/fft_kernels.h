@@ -256,7 +256,8 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(512, FFT_WAVES_PER_SIMD) tile_fft_kernel(Tile
     constexpr int SZ = (int)sizeof(cpx<T>);
     FFT_DYN_SMEM(smem);
 
-    const int tid = FFT_TID;
+    const int tid_invariant = FFT_TID;
+    const int tid = tid_invariant;
     const int nthreads = FFT_NTHREADS;
     const int log2L = FIXED ? (FIXED >> 8) : p.log2L;
     const int log2C = FIXED ? (FIXED & 255) : p.log2C;
@@ -266,8 +267,8 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(512, FFT_WAVES_PER_SIMD) tile_fft_kernel(Tile
     const int CG = 1 << log2CG;
     const int log2J = log2CG - log2V;
     const int J = 1 << log2J;
-    const int j = tid & (J - 1);
-    const int r = tid >> log2J;
+    const int j_invariant = tid & (J - 1);
+    const int r_invariant = tid >> log2J;
     const long long n_tiles = p.n_tiles;
     const long long tile_step = FFT_NBLOCKS;
 
@@ -297,6 +298,12 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(512, FFT_WAVES_PER_SIMD) tile_fft_kernel(Tile
     vec16<T> nxtbuf[DEPTH][H][E];
     auto prefetch = [&](long long tile, vec16<T> (&nxt)[H][E]) __attribute__((always_inline)) {
         const TileCoord<T> tc = tile_coord(p, tile);
+        int r = r_invariant, j = j_invariant, tid = tid_invariant;
+        if (E >= 16 || FFT_WAVES_PER_SIMD >= 4) {
+            FFT_OPAQUE(r);
+            FFT_OPAQUE(j);
+            FFT_OPAQUE(tid);
+        }
         FFT_UNROLL
         for (int h = 0; h < H; h++) {
             FFT_UNROLL
@@ -336,6 +343,15 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(512, FFT_WAVES_PER_SIMD) tile_fft_kernel(Tile
         const long long tile_ahead = tile + DEPTH * tile_step;
         const TileCoord<T> tc = tile_coord(p, tile);
         cpx<T> x[H][E][V];
+        // E = 16 only: hide the lane coordinates from the optimizer once per tile, otherwise LICM hoists every
+        // per-stage LDS address / twiddle index out of the persistent loop and keeps ~100 of them live (spills at
+        // 64 + 64 data VGPRs).  At E = 8 the hoisting fits the budget and SAVES the per-tile recomputation (+7 %).
+        int r = r_invariant, j = j_invariant, tid = tid_invariant;
+        if (E >= 16 || FFT_WAVES_PER_SIMD >= 4) {
+            FFT_OPAQUE(r);
+            FFT_OPAQUE(j);
+            FFT_OPAQUE(tid);
+        }
 
         // ---- consume the landed loads: slot e of group h <- element l = r + TPC*e
         if (LOADM == LOAD_CCONTIG) {
@@ -381,7 +397,7 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(512, FFT_WAVES_PER_SIMD) tile_fft_kernel(Tile
         // Next tile's loads.  E <= 8: a thread's tile share is 32 VGPRs, so the prefetch is issued right here and
         // flies during ALL of this tile's stages.  E == 16 (64 + 64 VGPRs would spill under the 2-waves-per-SIMD
         // budget): issued from inside the last group's stages, at the point where the data registers are dead.
-        constexpr bool EARLY = (E <= 8);
+        constexpr bool EARLY = (E <= 8) || (FAM != FAM_SR16);  // radix-2/4 codelets leave room for 64 + 64 data VGPRs
         const bool have_next = tile_ahead < n_tiles;
         if (EARLY && have_next) prefetch(tile_ahead, nxt);
         if (!(p.ablate & 2)) {
@@ -556,6 +572,96 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS(256)
         const cpx<T> a = xb[lo];
         xb[hi] = cscale(csub(a, pr), scale);
         xb[lo] = cscale(cadd(a, pr), scale);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// wave_dit_kernel -- the reference's radix-2 DIT pipeline (algorithms/core/radix2_dit.c:59-120: bit-reversal
+// permutation, then log2 n butterfly stages of stride 1, 2, 4, ...) held by ONE 64-lane wavefront per transform.
+//   1. coalesced HBM load, bit-reversal permutation through LDS (write at rev(i), read back contiguous):
+//      lane l then owns elements i = l*E .. l*E + E-1 of the permuted array (E = n/64);
+//   2. stages with butterfly stride < E run inside the lane's registers;
+//   3. stages with stride E .. 32E pair lane l with lane l ^ (stride/E): the partner's value arrives by
+//      __shfl_xor -- no LDS traffic and no barrier ("wavefront-level shuffle for the small-stride stages");
+//   4. every lane stores its E contiguous results.
+// Twiddles W_n^k (k < n/2) are staged in LDS once per workgroup.  n in {128, 256, 512, 1024}.
+// ---------------------------------------------------------------------------
+template <typename T, int E>
+FFT_KERNEL void FFT_LAUNCH_BOUNDS(256)
+    wave_dit_kernel(const cpx<T>* in, cpx<T>* out, const cpx<T>* tw_half, long long batch, int inverse, T scale) {
+    constexpr int N = 64 * E;
+    constexpr int LOG2N = 6 + Log2<E>::value;
+    constexpr int WAVES = 4;
+    FFT_DYN_SMEM(smem);
+    cpx<T>* tws = reinterpret_cast<cpx<T>*>(smem);                  // N/2 twiddles
+    cpx<T>* perm = reinterpret_cast<cpx<T>*>(smem) + N / 2;         // WAVES x N permutation image
+    const int tid = FFT_TID;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    for (int i = tid; i < N / 2; i += FFT_NTHREADS) tws[i] = tw_half[i];
+
+    for (long long t0 = FFT_BID * WAVES; t0 < batch; t0 += FFT_NBLOCKS * WAVES) {
+        const long long t = t0 + wave;
+        const bool live = t < batch;
+        cpx<T>* pw = perm + wave * N;
+        FFT_SYNC();  // tables visible / previous transform's image fully read
+        if (live) {
+            FFT_UNROLL
+            for (int e = 0; e < E; e++) {
+                const int i = lane + 64 * e;
+                cpx<T> v = in[t * N + i];
+                if (inverse) v = cswap(v);
+                pw[bitrev32((unsigned)i, LOG2N)] = v;
+            }
+        }
+        FFT_SYNC();
+        cpx<T> y[E];
+        FFT_UNROLL
+        for (int e = 0; e < E; e++) y[e] = live ? pw[lane * E + e] : mk<T>((T)0, (T)0);
+
+        // stages whose butterfly stride is inside the lane
+        FFT_UNROLL
+        for (int s = 1; s <= Log2<E>::value; s++) {
+            const int half = 1 << (s - 1);
+            FFT_UNROLL
+            for (int e = 0; e < E; e++) {
+                if ((e & half) == 0) {
+                    const int j = e & (half - 1);
+                    const cpx<T> w = tws[j << (LOG2N - s)];
+                    const cpx<T> tt = cmul(y[e + half], w);
+                    y[e + half] = csub(y[e], tt);
+                    y[e] = cadd(y[e], tt);
+                }
+            }
+        }
+        // stages whose partner lives in another lane of the same wavefront
+        FFT_UNROLL
+        for (int s = Log2<E>::value + 1; s <= LOG2N; s++) {
+            const int half = 1 << (s - 1);
+            const int lane_mask = half / E;
+            const bool is_bot = (lane & lane_mask) != 0;
+            FFT_UNROLL
+            for (int e = 0; e < E; e++) {
+                const int i = lane * E + e;
+                const int j = i & (half - 1);
+                const cpx<T> w = tws[j << (LOG2N - s)];
+                cpx<T> other;
+                other.re = FFT_SHFL_XOR(y[e].re, lane_mask);
+                other.im = FFT_SHFL_XOR(y[e].im, lane_mask);
+                const cpx<T> bot = is_bot ? y[e] : other;
+                const cpx<T> top = is_bot ? other : y[e];
+                const cpx<T> tt = cmul(bot, w);
+                y[e] = is_bot ? csub(top, tt) : cadd(top, tt);
+            }
+        }
+        if (live) {
+            FFT_UNROLL
+            for (int e = 0; e < E; e++) {
+                cpx<T> v = y[e];
+                if (inverse) v = cswap(v);
+                out[t * N + lane * E + e] = cscale(v, scale);
+            }
+        }
     }
 }
 

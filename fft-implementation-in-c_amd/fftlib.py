@@ -18,8 +18,8 @@ FFT_GPU_AUTO = -1
 FFT_GPU_HIP = 4
 PREC_F64 = 0
 PREC_F32 = 1
-ALGO_AUTO, ALGO_RADIX2, ALGO_RADIX4, ALGO_SPLIT_RADIX, ALGO_RADIX2_GLOBAL, ALGO_BLUESTEIN = range(6)
-ALGO_NAMES = {"auto": 0, "radix2": 1, "radix4": 2, "split_radix": 3, "radix2_global": 4, "bluestein": 5}
+ALGO_AUTO, ALGO_RADIX2, ALGO_RADIX4, ALGO_SPLIT_RADIX, ALGO_RADIX2_GLOBAL, ALGO_BLUESTEIN, ALGO_RADIX2_SHFL = range(7)
+ALGO_NAMES = {"auto": 0, "radix2": 1, "radix4": 2, "split_radix": 3, "radix2_global": 4, "bluestein": 5, "radix2_shfl": 6}
 FFT_PREFER_GPU = 1 << 9
 
 

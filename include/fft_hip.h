@@ -63,8 +63,11 @@ typedef enum {
     FFT_GPU_ALGO_SPLIT_RADIX = 3,   /* LDS Stockham, radix-8/16 passes with split-radix (L-shaped) codelets */
     FFT_GPU_ALGO_RADIX2_GLOBAL = 4, /* reference-shaped: bit-reversal permutation kernel + log2(n)
                                        in-place radix-2 DIT stage kernels in HBM (radix2_dit.c:70-112) */
-    FFT_GPU_ALGO_BLUESTEIN = 5      /* chirp-z even when n is a power of two (bluestein.c:79-155);
+    FFT_GPU_ALGO_BLUESTEIN = 5,     /* chirp-z even when n is a power of two (bluestein.c:79-155);
                                        every non-power-of-two n uses it whatever algo says */
+    FFT_GPU_ALGO_RADIX2_SHFL = 6    /* reference-shaped radix-2 DIT held by one wavefront per transform: LDS
+                                       bit-reversal permutation, in-register stages, __shfl_xor for the
+                                       cross-lane strides (n = 128..1024; other n: FFT_GPU_ALGO_RADIX2) */
 } fft_gpu_algo_t;
 
 typedef struct {

@@ -23,6 +23,8 @@ struct Runtime {
     int cus = 3;  // few "CUs" so that every workgroup walks several tiles (exercises the persistent loop + prefetch)
     int num_cus() { return cus; }
     void mark(int) {}
+    template <class K>
+    int max_blocks_per_cu(K, int, size_t) { return 1; }
     long long launches = 0;
 
     template <class K, class... A>

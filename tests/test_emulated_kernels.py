@@ -67,6 +67,17 @@ def test_three_pass_forced_by_small_lds():
     assert rel(y, oracle(xd, 1)) < 2e-14
 
 
+@pytest.mark.parametrize("n", [128, 256, 512, 1024])
+def test_one_wave_radix2_dit_with_shuffles(n):
+    """wave_dit_kernel: LDS bit-reversal permutation + in-register stages + __shfl_xor cross-lane stages."""
+    for dtype in (np.complex64, np.complex128):
+        x = O.gen_lcg(n, 9, 6).astype(dtype)  # 6 transforms: one and a half workgroups of 4 waves
+        for d in (-1, 1):
+            y, _ = E.emu_fft(x, d, 6)
+            assert rel(y, oracle(x, d)) < TOL[dtype]
+            assert rel(y, O.oracle_fft(x.astype(np.complex128), d, "dit")) < 1e-6  # the reference's own radix-2 path
+
+
 def test_bluestein_emulated():
     for n in (3, 31, 100, 1009):
         x = O.gen_lcg(n, n, 2)

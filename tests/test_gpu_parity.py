@@ -27,7 +27,7 @@ def lcg(n, batch, dtype, seed=0):
     return O.gen_lcg(n, seed, batch).astype(dtype)
 
 
-ALGOS = ["auto", "radix2", "radix4", "split_radix", "radix2_global"]
+ALGOS = ["auto", "radix2", "radix4", "split_radix", "radix2_global", "radix2_shfl"]
 
 
 @pytest.mark.parametrize("dtype", [np.complex128, np.complex64])
