@@ -46,7 +46,7 @@ struct PassDesc {
     int tw_levels = 2;  // inter-pass twiddle: 2- or 3-level table product
     int fam = 0;        // butterfly family of this pass (fftk::FAM_*)
     int sa_bits = 0, t0_bits = 0, t1_bits = 0, t2_bits = 0;
-    int o_sb = 0, o_t0 = 0, o_t1 = 0, o_t2 = 0, tables_elems = 0, off_tables = 0;
+    int o_sb = 0, o_t0 = 0, o_t1 = 0, o_t2 = 0, tables_elems = 0, off_tables = 0, group_bytes = 0;
     int loadm = 0, storem = 0, twiddle = 0;
     int n_ct = 1, n_o = 1;
     long long n_b_per_transform = 1;  // tiles along "b" contributed by ONE transform of the batch
@@ -72,7 +72,8 @@ inline int tile_E(long long L, int kind) {  // kind: 0 single-pass rows, 1 colum
         pref[0] = 8; pref[1] = 8; pref[2] = 8;
         if (const char* e = getenv("FFT_HIP_E")) sscanf(e, "%d,%d,%d", &pref[0], &pref[1], &pref[2]);
     }
-    int e = (pref[kind] == 16) ? 16 : 8;
+    int e = 8;
+    (void)pref;
     while (e > L) e >>= 1;
     return e;
 }
@@ -161,43 +162,57 @@ class Pow2Plan {
     }
 
     // ---- LDS footprint of one pass for a candidate group width CG = 2^log2CG
-    static int lds_bytes(PassDesc& p, int log2CG) {
+    static int lds_bytes(PassDesc& p, int log2CG, int log2H = 0) {
         const long long L = 1ll << p.log2L, CG = 1ll << log2CG;
         long long data = CG * L * SZ;
         if (p.loadm == fftk::LOAD_LCONTIG || p.storem == fftk::STORE_LCONTIG) data = CG * (L * SZ + 16);
-        long long off = (data + 15) & ~15ll;
+        data = (data + 15) & ~15ll;
+        p.group_bytes = (int)data;
+        long long off = data << log2H;
         p.off_tables = (int)off;
         off += (long long)layout_tables(p) * SZ;
         return off > 0x7fffffff ? 0x7fffffff : (int)off;
     }
 
-    // Choose the tile width C (columns per tile; all of them live in LDS at once, H = 1):
-    //  - threads = (C/V) * (L/E) <= 512 (the kernel is built for 2 waves per SIMD = 8 waves per CU);
-    //  - LDS <= the per-workgroup limit;
+    // Choose the tile: group width CG, H groups per tile (C = H * CG columns), thread count.
+    //  - threads = (CG/V) * (L/E) <= 512 (the kernels are built for 2 waves per SIMD = 8 waves per CU);
+    //  - H = 2 groups (each with its own LDS region, processed interleaved by the same threads) whenever that
+    //    fits LDS: doubles the row segment seen by HBM, halves the barriers per byte, doubles the bytes in flight;
     //  - stop widening once the row segment reaches 512 bytes (no measurable gain beyond, tools/membench).
     static bool choose_tile(PassDesc& p, long long extent_cols, int budget) {
         const int log2E = ilog2(p.E);
         const int log2V = ilog2(V);
-        int best = -1, best_levels = 2;
+        // two interleaved groups per tile (H = 2) were measured: the column pass gains 7 %, every row pass loses
+        // 20 %, and the pair is slower than H = 1 at every size tried -- kept behind FFT_HIP_GROUPS=1 for experiments
+        static const int no_groups = getenv("FFT_HIP_GROUPS") ? 0 : 1;
+        int best = -1, best_levels = 2, best_h = 0;
+        long long best_c = 0;
         for (int levels = 2; levels <= 3; levels++) {
             p.tw_levels = levels;
-            int cand = -1;
-            for (int lc = log2V; (1ll << lc) <= extent_cols || lc == log2V; lc++) {
-                const long long threads = (1ll << (lc - log2V)) << (p.log2L - log2E);
-                if (threads > 512) break;
-                if (lds_bytes(p, lc) > budget) break;
-                cand = lc;
-                if ((1ll << lc) * SZ >= 512 && threads >= 256) break;
+            // two interleaved groups pay off for the column pass only (measured: row passes get slower)
+            static const int groups_mask = getenv("FFT_HIP_GROUPS") ? atoi(getenv("FFT_HIP_GROUPS")) : 0;  // bit0 column pass, bit1 row passes
+            const int want = (p.loadm == fftk::LOAD_CCONTIG) ? (groups_mask & 1) : (groups_mask & 2);
+            for (int lh = (p.E == 8 && !no_groups && want) ? 1 : 0; lh >= 0; lh--) {
+                int cand = -1;
+                for (int lc = log2V; (1ll << (lc + lh)) <= extent_cols || (lc == log2V && lh == 0); lc++) {
+                    const long long threads = (1ll << (lc - log2V)) << (p.log2L - log2E);
+                    if (threads > 512) break;
+                    if (lds_bytes(p, lc, lh) > budget) break;
+                    cand = lc;
+                    if ((1ll << (lc + lh)) * SZ >= 512 && threads >= 256) break;
+                }
+                if (cand >= 0 && (1ll << (cand + lh)) > best_c) {
+                    best = cand; best_h = lh; best_levels = levels; best_c = 1ll << (cand + lh);
+                }
             }
-            if (cand > best) { best = cand; best_levels = levels; }
             if (!p.twiddle) break;
         }
         if (best < 0) return false;
         p.tw_levels = best_levels;
-        p.log2H = 0;
-        p.log2C = best;
+        p.log2H = best_h;
+        p.log2C = best + best_h;
         p.nthreads = (int)((1ll << (best - log2V)) << (p.log2L - log2E));
-        p.smem_bytes = lds_bytes(p, best);
+        p.smem_bytes = lds_bytes(p, best, best_h);
         long long seg = (1ll << p.log2C) * SZ;
         p.seg_bytes = (int)(seg > 1 << 20 ? 1 << 20 : seg);
         return true;
@@ -404,7 +419,13 @@ class Pow2Plan {
 
     template <int E, int FAM, int LM, int SM, bool TW>
     void launch_one(const fftk::TileParams<T>& tp, long long grid, const PassDesc& p) {
-        auto kernel = fftk::tile_fft_kernel<T, E, 1, FAM, LM, SM, TW, 0>;
+        if (E == 8 && p.log2H == 1) launch_one_h<E, (E == 8 ? 2 : 1), FAM, LM, SM, TW>(tp, grid, p);
+        else launch_one_h<E, 1, FAM, LM, SM, TW>(tp, grid, p);
+    }
+
+    template <int E, int H, int FAM, int LM, int SM, bool TW>
+    void launch_one_h(const fftk::TileParams<T>& tp, long long grid, const PassDesc& p) {
+        auto kernel = fftk::tile_fft_kernel<T, E, H, FAM, LM, SM, TW, 0>;
         if (grid < 0) {
             // persistent grid: exactly the workgroups that are resident at once (occupancy query: VGPRs, LDS, waves)
             int per_cu = rt->max_blocks_per_cu(kernel, p.nthreads, (size_t)p.smem_bytes);
@@ -423,8 +444,7 @@ class Pow2Plan {
         switch (p.E) {
             case 2: launch_one<2, FAM_R2, LM, SM, TW>(tp, grid, p); break;
             case 4: launch_one<4, (FAM == FAM_SR16 ? FAM_R4 : FAM), LM, SM, TW>(tp, grid, p); break;
-            case 8: launch_one<8, FAM, LM, SM, TW>(tp, grid, p); break;
-            default: launch_one<16, (FAM == FAM_SR16 ? FAM_R4 : FAM), LM, SM, TW>(tp, grid, p); break;  // E = 16: radix-4 / radix-2 only
+            default: launch_one<8, FAM, LM, SM, TW>(tp, grid, p); break;
         }
     }
 
@@ -444,6 +464,7 @@ class Pow2Plan {
         tp.out = out;
         tp.tables = pass_tables[ipass];
         tp.tables_bytes = p.tables_elems * SZ;
+        tp.group_bytes = p.group_bytes;
         tp.off_tables = p.off_tables;
         tp.o_sb = p.o_sb; tp.o_t0 = p.o_t0; tp.o_t1 = p.o_t1; tp.o_t2 = p.o_t2;
         tp.sa_bits = p.sa_bits; tp.t0_bits = p.t0_bits; tp.t1_bits = p.t1_bits; tp.t2_bits = p.t2_bits;

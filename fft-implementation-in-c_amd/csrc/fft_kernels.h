@@ -49,6 +49,7 @@ struct TileParams {
     const cpx<T>* in;
     cpx<T>* out;
     const cpx<T>* tables;  // device copy of the blob
+    int group_bytes;       // LDS bytes reserved per column group (multiple of 16)
     int tables_bytes;      // multiple of 16
     int off_tables;        // byte offset of the blob's LDS copy
     int o_sb, o_t0, o_t1, o_t2;  // element offsets inside the blob (sa at 0)
@@ -105,41 +106,49 @@ struct StageTw {
 // After the last stage slot e holds frequency K = r + TPC*e -- the same shape
 // the inputs were loaded in, so a c-contiguous store needs no further exchange.
 // ---------------------------------------------------------------------------
-template <typename T, int E, int R, int V>
-FFT_DEVICE void stockham_stage(cpx<T> (&x)[E][V], unsigned char* smem, const StageTw<T>& tw, int r, int j, int log2J,
-                               int log2TPC, int& log2Lprev, int& log2P, bool first, bool last) {
+template <typename T, int E, int R, int V, int H>
+FFT_DEVICE void stockham_stage(cpx<T> (&x)[H][E][V], unsigned char* smem, int group_bytes, const StageTw<T>& tw, int r,
+                               int j, int log2J, int log2TPC, int& log2Lprev, int& log2P, bool first, bool last) {
+    // The H column groups of a tile go through every phase TOGETHER (own LDS region each, shared barriers):
+    // twice the independent work between two barriers, half the barriers per byte.
     constexpr int G = E / R;
     constexpr int log2R = Log2<R>::value;
     const int log2Li = log2Lprev - log2R;
     const int Li_mask = (1 << log2Li) - 1;
-    vec16<T>* data = reinterpret_cast<vec16<T>*>(smem);
 
     if (!first) {
         FFT_UNROLL
-        for (int m = 0; m < G; m++) {
-            const int u = r + (m << log2TPC);
-            const int q = u & Li_mask;
-            const int kp = u >> log2Li;
-            const int base = (kp << log2Lprev) + q;
+        for (int h = 0; h < H; h++) {
+            const vec16<T>* data = reinterpret_cast<const vec16<T>*>(smem + h * group_bytes);
             FFT_UNROLL
-            for (int a = 0; a < R; a++) {
-                vec16<T> v = data[((base + (a << log2Li)) << log2J) + j];
+            for (int m = 0; m < G; m++) {
+                const int u = r + (m << log2TPC);
+                const int q = u & Li_mask;
+                const int kp = u >> log2Li;
+                const int base = (kp << log2Lprev) + q;
                 FFT_UNROLL
-                for (int vv = 0; vv < V; vv++) x[m + G * a][vv] = v.c[vv];
+                for (int a = 0; a < R; a++) {
+                    vec16<T> v = data[((base + (a << log2Li)) << log2J) + j];
+                    FFT_UNROLL
+                    for (int vv = 0; vv < V; vv++) x[h][m + G * a][vv] = v.c[vv];
+                }
             }
         }
     }
 
     FFT_UNROLL
-    for (int m = 0; m < G; m++) {
+    for (int h = 0; h < H; h++) {
         FFT_UNROLL
-        for (int vv = 0; vv < V; vv++) {
-            cpx<T> t[R];
+        for (int m = 0; m < G; m++) {
             FFT_UNROLL
-            for (int a = 0; a < R; a++) t[a] = x[m + G * a][vv];
-            dft_inplace<T, R>(t);
-            FFT_UNROLL
-            for (int a = 0; a < R; a++) x[m + G * a][vv] = t[a];
+            for (int vv = 0; vv < V; vv++) {
+                cpx<T> t[R];
+                FFT_UNROLL
+                for (int a = 0; a < R; a++) t[a] = x[h][m + G * a][vv];
+                dft_inplace<T, R>(t);
+                FFT_UNROLL
+                for (int a = 0; a < R; a++) x[h][m + G * a][vv] = t[a];
+            }
         }
     }
 
@@ -151,24 +160,31 @@ FFT_DEVICE void stockham_stage(cpx<T> (&x)[E][V], unsigned char* smem, const Sta
             const int tq = q << log2P;
             FFT_UNROLL
             for (int k = 1; k < R; k++) {
-                const cpx<T> w = tw.get(tq * k);
+                const cpx<T> w = tw.get(tq * k);  // one lookup serves all groups and both columns
                 FFT_UNROLL
-                for (int vv = 0; vv < V; vv++) x[m + G * k][vv] = cmul(x[m + G * k][vv], w);
+                for (int h = 0; h < H; h++) {
+                    FFT_UNROLL
+                    for (int vv = 0; vv < V; vv++) x[h][m + G * k][vv] = cmul(x[h][m + G * k][vv], w);
+                }
             }
         }
         if (!first) FFT_SYNC_LDS();  // everyone has finished reading the previous exchange
         FFT_UNROLL
-        for (int m = 0; m < G; m++) {
-            const int u = r + (m << log2TPC);
-            const int q = u & Li_mask;
-            const int kp = u >> log2Li;
+        for (int h = 0; h < H; h++) {
+            vec16<T>* data = reinterpret_cast<vec16<T>*>(smem + h * group_bytes);
             FFT_UNROLL
-            for (int k = 0; k < R; k++) {
-                vec16<T> v;
+            for (int m = 0; m < G; m++) {
+                const int u = r + (m << log2TPC);
+                const int q = u & Li_mask;
+                const int kp = u >> log2Li;
                 FFT_UNROLL
-                for (int vv = 0; vv < V; vv++) v.c[vv] = x[m + G * k][vv];
-                const int idx = ((kp + (k << log2P)) << log2Li) + q;
-                data[(idx << log2J) + j] = v;
+                for (int k = 0; k < R; k++) {
+                    vec16<T> v;
+                    FFT_UNROLL
+                    for (int vv = 0; vv < V; vv++) v.c[vv] = x[h][m + G * k][vv];
+                    const int idx = ((kp + (k << log2P)) << log2Li) + q;
+                    data[(idx << log2J) + j] = v;
+                }
             }
         }
         FFT_SYNC_LDS();
@@ -179,10 +195,10 @@ FFT_DEVICE void stockham_stage(cpx<T> (&x)[E][V], unsigned char* smem, const Sta
 
 // All stages of one tile.  `before_last` runs once, right before the LAST stage reads its inputs from
 // LDS (or before the only stage): at that point the thread's data registers are dead (everything sits in
-// LDS), which is where the kernel issues the next tile's prefetch without raising the register peak.
-template <typename T, int E, int FAM, int V, class F>
-FFT_DEVICE void stockham_all_stages(cpx<T> (&x)[E][V], unsigned char* smem, const StageTw<T>& tw, int r, int j,
-                                    int log2J, int log2TPC, int log2L, F&& before_last) {
+// LDS), which is where the E = 16 kernels issue the next tile's prefetch without raising the register peak.
+template <typename T, int E, int FAM, int V, int H, class F>
+FFT_DEVICE void stockham_all_stages(cpx<T> (&x)[H][E][V], unsigned char* smem, int group_bytes, const StageTw<T>& tw,
+                                    int r, int j, int log2J, int log2TPC, int log2L, F&& before_last) {
     constexpr int RM = (FAM == FAM_SR16) ? E : (FAM == FAM_R4 ? (E < 4 ? E : 4) : 2);
     constexpr int log2RM = Log2<RM>::value;
     int log2Lprev = log2L, log2P = 0;
@@ -192,15 +208,15 @@ FFT_DEVICE void stockham_all_stages(cpx<T> (&x)[E][V], unsigned char* smem, cons
     FFT_UNROLL
     for (int s = 0; s < n_full; s++) {
         if (s == total - 1) before_last();
-        stockham_stage<T, E, RM, V>(x, smem, tw, r, j, log2J, log2TPC, log2Lprev, log2P, s == 0, s == total - 1);
+        stockham_stage<T, E, RM, V, H>(x, smem, group_bytes, tw, r, j, log2J, log2TPC, log2Lprev, log2P, s == 0, s == total - 1);
     }
     if (rem) before_last();
     if (RM > 2 && rem == 1)
-        stockham_stage<T, E, 2, V>(x, smem, tw, r, j, log2J, log2TPC, log2Lprev, log2P, total == 1, true);
+        stockham_stage<T, E, 2, V, H>(x, smem, group_bytes, tw, r, j, log2J, log2TPC, log2Lprev, log2P, total == 1, true);
     if (RM > 4 && rem == 2)
-        stockham_stage<T, E, (RM > 4 ? 4 : 2), V>(x, smem, tw, r, j, log2J, log2TPC, log2Lprev, log2P, total == 1, true);
+        stockham_stage<T, E, (RM > 4 ? 4 : 2), V, H>(x, smem, group_bytes, tw, r, j, log2J, log2TPC, log2Lprev, log2P, total == 1, true);
     if (RM > 8 && rem == 3)
-        stockham_stage<T, E, (RM > 8 ? 8 : 2), V>(x, smem, tw, r, j, log2J, log2TPC, log2Lprev, log2P, total == 1, true);
+        stockham_stage<T, E, (RM > 8 ? 8 : 2), V, H>(x, smem, group_bytes, tw, r, j, log2J, log2TPC, log2Lprev, log2P, total == 1, true);
 }
 
 // ---------------------------------------------------------------------------
@@ -286,6 +302,7 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(512, FFT_WAVES_PER_SIMD) tile_fft_kernel(Tile
     tw.log2L = log2L;
 
     const int pitch = L * SZ + 16;      // raw-row pitch of the l-contiguous staging image
+    const int group_bytes = p.group_bytes;  // LDS bytes of one column group (exchange area or staging image)
     const int log2CPR = log2L - log2V;  // 16-byte chunks per row (L >= V always)
     const int cpr_mask = (1 << log2CPR) - 1;
 
@@ -299,7 +316,7 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(512, FFT_WAVES_PER_SIMD) tile_fft_kernel(Tile
     auto prefetch = [&](long long tile, vec16<T> (&nxt)[H][E]) __attribute__((always_inline)) {
         const TileCoord<T> tc = tile_coord(p, tile);
         int r = r_invariant, j = j_invariant, tid = tid_invariant;
-        if (E >= 16 || FFT_WAVES_PER_SIMD >= 4) {
+        if (E * H >= 16 || FFT_WAVES_PER_SIMD >= 4) {
             FFT_OPAQUE(r);
             FFT_OPAQUE(j);
             FFT_OPAQUE(tid);
@@ -347,7 +364,7 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(512, FFT_WAVES_PER_SIMD) tile_fft_kernel(Tile
         // per-stage LDS address / twiddle index out of the persistent loop and keeps ~100 of them live (spills at
         // 64 + 64 data VGPRs).  At E = 8 the hoisting fits the budget and SAVES the per-tile recomputation (+7 %).
         int r = r_invariant, j = j_invariant, tid = tid_invariant;
-        if (E >= 16 || FFT_WAVES_PER_SIMD >= 4) {
+        if (E * H >= 16 || FFT_WAVES_PER_SIMD >= 4) {
             FFT_OPAQUE(r);
             FFT_OPAQUE(j);
             FFT_OPAQUE(tid);
@@ -364,25 +381,37 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(512, FFT_WAVES_PER_SIMD) tile_fft_kernel(Tile
                 }
             }
         } else {
+            FFT_SYNC_LDS();  // the previous user of the LDS regions (last tile's store image / last exchange) is done
             FFT_UNROLL
             for (int h = 0; h < H; h++) {
-                FFT_SYNC_LDS();  // the previous user of the exchange area (last tile's store image / previous group) is done
                 FFT_UNROLL
                 for (int i = 0; i < E; i++) {
                     const int g = tid + i * nthreads;
-                    *reinterpret_cast<vec16<T>*>(smem + (size_t)(g >> log2CPR) * pitch + (size_t)(g & cpr_mask) * 16) = nxt[h][i];
+                    *reinterpret_cast<vec16<T>*>(smem + h * group_bytes + (size_t)(g >> log2CPR) * pitch +
+                                                 (size_t)(g & cpr_mask) * 16) = nxt[h][i];
                 }
-                FFT_SYNC_LDS();
+            }
+            FFT_SYNC_LDS();
+            FFT_UNROLL
+            for (int h = 0; h < H; h++) {
                 FFT_UNROLL
                 for (int e = 0; e < E; e++) {
                     const int l = r + (e << log2TPC);
                     FFT_UNROLL
                     for (int vv = 0; vv < V; vv++)
-                        x[h][e][vv] = *reinterpret_cast<const cpx<T>*>(smem + (size_t)(V * j + vv) * pitch + (size_t)l * SZ);
+                        x[h][e][vv] = *reinterpret_cast<const cpx<T>*>(smem + h * group_bytes + (size_t)(V * j + vv) * pitch +
+                                                                       (size_t)l * SZ);
                 }
             }
         }
-        if (p.inverse) {
+        // Next tile's loads.  E <= 8: a thread's tile share is 32 VGPRs, so the prefetch is issued right here and
+        // flies during ALL of this tile's stages.  E == 16 (64 + 64 VGPRs would spill under the 2-waves-per-SIMD
+        // budget): issued from inside the last group's stages, at the point where the data registers are dead.
+        constexpr bool EARLY = (E <= 8) || (FAM != FAM_SR16);  // radix-2/4 codelets leave room for 64 + 64 data VGPRs
+        const bool have_next = tile_ahead < n_tiles;
+        if (EARLY && have_next) prefetch(tile_ahead, nxt);
+
+        if (p.inverse) {  // inverse = forward transform between two re<->im swaps
             FFT_UNROLL
             for (int h = 0; h < H; h++) {
                 FFT_UNROLL
@@ -393,25 +422,11 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(512, FFT_WAVES_PER_SIMD) tile_fft_kernel(Tile
             }
         }
 
-        // ---- stages, one column group at a time through the same LDS exchange area
-        // Next tile's loads.  E <= 8: a thread's tile share is 32 VGPRs, so the prefetch is issued right here and
-        // flies during ALL of this tile's stages.  E == 16 (64 + 64 VGPRs would spill under the 2-waves-per-SIMD
-        // budget): issued from inside the last group's stages, at the point where the data registers are dead.
-        constexpr bool EARLY = (E <= 8) || (FAM != FAM_SR16);  // radix-2/4 codelets leave room for 64 + 64 data VGPRs
-        const bool have_next = tile_ahead < n_tiles;
-        if (EARLY && have_next) prefetch(tile_ahead, nxt);
         if (!(p.ablate & 2)) {
-            FFT_UNROLL
-            for (int h = 0; h < H; h++) {
-                FFT_SYNC_LDS();  // staging image / previous group's last exchange / previous tile fully consumed
-                if (h == H - 1) {
-                    stockham_all_stages<T, E, FAM, V>(x[h], smem, tw, r, j, log2J, log2TPC, log2L, [&]() {
-                        if (!EARLY && have_next) prefetch(tile_ahead, nxt);
-                    });
-                } else {
-                    stockham_all_stages<T, E, FAM, V>(x[h], smem, tw, r, j, log2J, log2TPC, log2L, []() {});
-                }
-            }
+            FFT_SYNC_LDS();  // staging image / previous tile's last exchange fully consumed
+            stockham_all_stages<T, E, FAM, V, H>(x, smem, group_bytes, tw, r, j, log2J, log2TPC, log2L, [&]() {
+                if (!EARLY && have_next) prefetch(tile_ahead, nxt);
+            });
         } else if (!EARLY && have_next) {
             prefetch(tile_ahead, nxt);
         }
@@ -492,17 +507,20 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(512, FFT_WAVES_PER_SIMD) tile_fft_kernel(Tile
                 }
             }
         } else {
+            FFT_SYNC_LDS();  // last exchange fully consumed
             FFT_UNROLL
             for (int h = 0; h < H; h++) {
-                FFT_SYNC_LDS();  // last exchange (or the previous group's image) fully consumed
                 FFT_UNROLL
                 for (int e = 0; e < E; e++) {
                     const int K = r + (e << log2TPC);
                     FFT_UNROLL
                     for (int vv = 0; vv < V; vv++)
-                        *reinterpret_cast<cpx<T>*>(smem + (size_t)(V * j + vv) * pitch + (size_t)K * SZ) = x[h][e][vv];
+                        *reinterpret_cast<cpx<T>*>(smem + h * group_bytes + (size_t)(V * j + vv) * pitch + (size_t)K * SZ) = x[h][e][vv];
                 }
-                FFT_SYNC_LDS();
+            }
+            FFT_SYNC_LDS();
+            FFT_UNROLL
+            for (int h = 0; h < H; h++) {
                 FFT_UNROLL
                 for (int i = 0; i < E; i++) {
                     const int g = tid + i * nthreads;
@@ -510,7 +528,8 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(512, FFT_WAVES_PER_SIMD) tile_fft_kernel(Tile
                     const int pos = g & cpr_mask;
                     if (tc.c0 + t < p.n_cols)
                         *reinterpret_cast<vec16<T>*>(tc.out + (long long)t * p.out_c + (long long)pos * V) =
-                            *reinterpret_cast<const vec16<T>*>(smem + (size_t)(g >> log2CPR) * pitch + (size_t)pos * 16);
+                            *reinterpret_cast<const vec16<T>*>(smem + h * group_bytes + (size_t)(g >> log2CPR) * pitch +
+                                                               (size_t)pos * 16);
                 }
             }
         }
