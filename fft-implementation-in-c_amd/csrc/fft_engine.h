@@ -288,7 +288,11 @@ class Pow2Plan {
             const int l2 = log2n - l1;
             if (n_force >= 1 && !(n_force == 2 && force[0] == l1)) continue;
             PassDesc a, b;
-            a.log2L = l1; a.E = tile_E(1ll << l1, 1); a.loadm = fftk::LOAD_CCONTIG; a.storem = fftk::STORE_CCONTIG; a.twiddle = 1; a.log2Ntw = log2n;
+            // W_n^(k1 n2) is applied by the column pass (A) to its results; applying it in the row pass (B) at load was
+            // measured slower for BOTH kernels (0.78 + 0.59 vs 0.69 + 0.51 ms) -- kept behind FFT_HIP_TWIDDLE_IN_B
+            static const int tw_in_b = getenv("FFT_HIP_TWIDDLE_IN_B") ? 1 : 0;
+            a.log2L = l1; a.E = tile_E(1ll << l1, 1); a.loadm = fftk::LOAD_CCONTIG; a.storem = fftk::STORE_CCONTIG; a.twiddle = tw_in_b ? 0 : 1; a.log2Ntw = log2n;
+            b.twiddle = tw_in_b ? 1 : 0; b.log2Ntw = log2n;
             a.in_b = n; a.in_c = 1; a.in_l = 1ll << l2; a.out_b = n; a.out_c = 1; a.out_k = 1ll << l2;
             a.n_cols = 1 << l2;
             if (!choose_tile(a, 1ll << l2, budget)) continue;
@@ -451,9 +455,15 @@ class Pow2Plan {
     template <int FAM, int H>
     void launch_fam(const fftk::TileParams<T>& tp, long long grid, const PassDesc& p) {
         using namespace fftk;
-        if (p.loadm == LOAD_CCONTIG) launch_mode<FAM, LOAD_CCONTIG, STORE_CCONTIG, true>(tp, grid, p);
-        else if (p.storem == STORE_CCONTIG) launch_mode<FAM, LOAD_LCONTIG, STORE_CCONTIG, false>(tp, grid, p);
-        else launch_mode<FAM, LOAD_LCONTIG, STORE_LCONTIG, false>(tp, grid, p);
+        if (p.loadm == LOAD_CCONTIG) {
+            if (p.twiddle) launch_mode<FAM, LOAD_CCONTIG, STORE_CCONTIG, true>(tp, grid, p);
+            else launch_mode<FAM, LOAD_CCONTIG, STORE_CCONTIG, false>(tp, grid, p);
+        } else if (p.storem == STORE_CCONTIG) {
+            if (p.twiddle) launch_mode<FAM, LOAD_LCONTIG, STORE_CCONTIG, true>(tp, grid, p);
+            else launch_mode<FAM, LOAD_LCONTIG, STORE_CCONTIG, false>(tp, grid, p);
+        } else {
+            launch_mode<FAM, LOAD_LCONTIG, STORE_LCONTIG, false>(tp, grid, p);
+        }
     }
 
     void launch_pass(size_t ipass, const cpx<T>* in, cpx<T>* out, int nb, bool inverse, T scale) {
@@ -478,7 +488,9 @@ class Pow2Plan {
         tp.inverse = inverse ? 1 : 0;
         tp.scale = scale;
         static const int ablate = getenv("FFT_HIP_ABLATE") ? atoi(getenv("FFT_HIP_ABLATE")) : 0;  // profiling only
-        tp.ablate = ablate;
+        tp.ablate = ablate & ~48;
+        if (passes.size() == 2 && ipass == 0) tp.ablate |= (ablate & 16);  // experiment: pass A writes a wrapped (cache-sized) scratch
+        if (passes.size() == 2 && ipass == 1) tp.ablate |= (ablate & 32);  // experiment: pass B reads it
         static const int pair16 = getenv("FFT_HIP_PAIR16") ? atoi(getenv("FFT_HIP_PAIR16")) : 0;
         tp.pair16 = (pair16 && ((1ll << p.log2C) * SZ < 128)) ? 1 : 0;
         if (p.n_cols < 0) {  // single-pass row kernel: columns are the transforms of the batch

@@ -20,6 +20,9 @@ namespace fftk {
 #ifndef FFT_WAVES_PER_SIMD
 #define FFT_WAVES_PER_SIMD 2
 #endif
+#ifndef FFT_FORCE_OPAQUE
+#define FFT_FORCE_OPAQUE 0
+#endif
 enum { LOAD_CCONTIG = 0, LOAD_LCONTIG = 1 };
 enum { STORE_CCONTIG = 0, STORE_LCONTIG = 1 };
 enum { FAM_SR16 = 0, FAM_R4 = 1, FAM_R2 = 2 };
@@ -256,8 +259,11 @@ FFT_DEVICE TileCoord<T> tile_coord(const TileParams<T>& p, long long tile) {
     const unsigned o = rest % (unsigned)p.n_o;
     const long long b = rest / (unsigned)p.n_o;
     tc.c0 = ct << p.log2C;
-    tc.in = p.in + b * p.in_b + o * p.in_o + (long long)tc.c0 * p.in_c;
-    tc.out = p.out + b * p.out_b + o * p.out_o + (long long)tc.c0 * p.out_c;
+    long long boff_in = b * p.in_b, boff_out = b * p.out_b;
+    if (p.ablate & 16) boff_out %= (8 * p.out_b);  // timing experiment only: scratch side wraps into 8 transforms (cache-resident)
+    if (p.ablate & 32) boff_in %= (8 * p.in_b);
+    tc.in = p.in + boff_in + o * p.in_o + (long long)tc.c0 * p.in_c;
+    tc.out = p.out + boff_out + o * p.out_o + (long long)tc.c0 * p.out_c;
     return tc;
 }
 
@@ -311,12 +317,15 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(512, FFT_WAVES_PER_SIMD) tile_fft_kernel(Tile
     //   LOAD_LCONTIG: nxt[h][i] = chunk g = tid + i*nthreads of the group's contiguous rows
     //                 (CG rows * L/V chunks == nthreads * E, so every thread moves exactly E chunks)
     // DEPTH tiles are kept in flight per workgroup (double-buffered prefetch registers when E <= 8).
-    constexpr int DEPTH = 1;  // 2 was tried (double-buffered prefetch): +32 VGPRs tipped the l-contiguous kernels into spills, 20% slower
+#ifndef FFT_DEPTH
+#define FFT_DEPTH 1
+#endif
+    constexpr int DEPTH = FFT_DEPTH;  // 2 = double-buffered prefetch (+32 VGPRs; needs FFT_FORCE_OPAQUE to stay spill-free)
     vec16<T> nxtbuf[DEPTH][H][E];
     auto prefetch = [&](long long tile, vec16<T> (&nxt)[H][E]) __attribute__((always_inline)) {
         const TileCoord<T> tc = tile_coord(p, tile);
         int r = r_invariant, j = j_invariant, tid = tid_invariant;
-        if (E * H >= 16 || FFT_WAVES_PER_SIMD >= 4) {
+        if (E * H >= 16 || FFT_WAVES_PER_SIMD >= 4 || FFT_FORCE_OPAQUE) {
             FFT_OPAQUE(r);
             FFT_OPAQUE(j);
             FFT_OPAQUE(tid);
@@ -349,6 +358,30 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(512, FFT_WAVES_PER_SIMD) tile_fft_kernel(Tile
         }
     };
 
+    // x[h][e][v] *= W_Ntw^(row * column): row = r + TPC*e is the index along the transformed axis (frequency K in
+    // a column pass, sample l in a row pass), column = the tile column.  Two- or three-level LDS tables.
+    auto interpass_twiddle = [&](cpx<T> (&x)[H][E][V], int c0, int r, int j) __attribute__((always_inline)) {
+        const cpx<T>* t0 = tab + p.o_t0;
+        const cpx<T>* t1 = tab + p.o_t1;
+        const cpx<T>* t2 = tab + p.o_t2;
+        const unsigned m0 = (1u << p.t0_bits) - 1u, m1 = (1u << p.t1_bits) - 1u;
+        const int sh2 = p.t0_bits + p.t1_bits;
+        FFT_UNROLL
+        for (int h = 0; h < H; h++) {
+            FFT_UNROLL
+            for (int e = 0; e < E; e++) {
+                const unsigned K = (unsigned)(r + (e << log2TPC));
+                FFT_UNROLL
+                for (int vv = 0; vv < V; vv++) {
+                    const unsigned m = K * (unsigned)(c0 + h * CG + V * j + vv);
+                    cpx<T> w = cmul(t0[m & m0], t1[(m >> p.t0_bits) & m1]);
+                    if (p.t2_bits) w = cmul(w, t2[m >> sh2]);
+                    x[h][e][vv] = cmul(x[h][e][vv], w);
+                }
+            }
+        }
+    };
+
     long long tile0 = FFT_BID;
     FFT_UNROLL
     for (int d = 0; d < DEPTH; d++)
@@ -364,7 +397,7 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(512, FFT_WAVES_PER_SIMD) tile_fft_kernel(Tile
         // per-stage LDS address / twiddle index out of the persistent loop and keeps ~100 of them live (spills at
         // 64 + 64 data VGPRs).  At E = 8 the hoisting fits the budget and SAVES the per-tile recomputation (+7 %).
         int r = r_invariant, j = j_invariant, tid = tid_invariant;
-        if (E * H >= 16 || FFT_WAVES_PER_SIMD >= 4) {
+        if (E * H >= 16 || FFT_WAVES_PER_SIMD >= 4 || FFT_FORCE_OPAQUE) {
             FFT_OPAQUE(r);
             FFT_OPAQUE(j);
             FFT_OPAQUE(tid);
@@ -422,6 +455,11 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(512, FFT_WAVES_PER_SIMD) tile_fft_kernel(Tile
             }
         }
 
+        // row pass of a multi-pass plan: the inter-pass twiddle W_N^(k1 * n2) is applied HERE, to the loaded samples
+        // (n2 = r + TPC*e runs along the row, k1 = the tile column) -- this pass hides arithmetic behind its memory
+        // traffic, the column pass before it does not
+        if (TWIDDLE && LOADM == LOAD_LCONTIG && !(p.ablate & 1)) interpass_twiddle(x, tc.c0, r, j);
+
         if (!(p.ablate & 2)) {
             FFT_SYNC_LDS();  // staging image / previous tile's last exchange fully consumed
             stockham_all_stages<T, E, FAM, V, H>(x, smem, group_bytes, tw, r, j, log2J, log2TPC, log2L, [&]() {
@@ -448,28 +486,8 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(512, FFT_WAVES_PER_SIMD) tile_fft_kernel(Tile
         }
 #endif
 
-        // ---- inter-pass twiddle W_Ntw^(K * column), scale, inverse swap
-        if (TWIDDLE && !(p.ablate & 1)) {
-            const cpx<T>* t0 = tab + p.o_t0;
-            const cpx<T>* t1 = tab + p.o_t1;
-            const cpx<T>* t2 = tab + p.o_t2;
-            const unsigned m0 = (1u << p.t0_bits) - 1u, m1 = (1u << p.t1_bits) - 1u;
-            const int sh2 = p.t0_bits + p.t1_bits;
-            FFT_UNROLL
-            for (int h = 0; h < H; h++) {
-                FFT_UNROLL
-                for (int e = 0; e < E; e++) {
-                    const unsigned K = (unsigned)(r + (e << log2TPC));
-                    FFT_UNROLL
-                    for (int vv = 0; vv < V; vv++) {
-                        const unsigned m = K * (unsigned)(tc.c0 + h * CG + V * j + vv);
-                        cpx<T> w = cmul(t0[m & m0], t1[(m >> p.t0_bits) & m1]);
-                        if (p.t2_bits) w = cmul(w, t2[m >> sh2]);
-                        x[h][e][vv] = cmul(x[h][e][vv], w);
-                    }
-                }
-            }
-        }
+        // ---- inter-pass twiddle (column pass: applied to the results, before the store), scale, inverse swap
+        if (TWIDDLE && LOADM == LOAD_CCONTIG && !(p.ablate & 1)) interpass_twiddle(x, tc.c0, r, j);
         if (p.inverse) {
             FFT_UNROLL
             for (int h = 0; h < H; h++) {
