@@ -429,7 +429,36 @@ class Pow2Plan {
 
     template <int E, int H, int FAM, int LM, int SM, bool TW>
     void launch_one_h(const fftk::TileParams<T>& tp, long long grid, const PassDesc& p) {
-        auto kernel = fftk::tile_fft_kernel<T, E, H, FAM, LM, SM, TW, 0>;
+        // Hot shapes get an instantiation with L and C baked in (every shift / mask / LDS offset becomes an
+        // immediate: fewer integer VALU ops and address VGPRs; measured +9 % at N = 2^20).  Shapes: the full
+        // 64 KiB tile of L in {128, 256, 512, 1024} in AUTO's families, column pass and transposing row pass.
+        constexpr bool HAS_FIX = (E == 8 && H == 1) &&
+                                 ((LM == fftk::LOAD_CCONTIG && FAM == fftk::FAM_R4 && TW) ||
+                                  (LM == fftk::LOAD_LCONTIG && SM == fftk::STORE_CCONTIG && FAM == fftk::FAM_SR16 && !TW));
+        static const int use_fixed = getenv("FFT_HIP_FIXED") ? atoi(getenv("FFT_HIP_FIXED")) : 1;
+        if (HAS_FIX && use_fixed) {
+            const int full_c = 13 - ilog2(SZ / 8) - p.log2L;  // log2 of (8192 or 4096 elements) / L
+            if (p.log2C == full_c) {
+                switch (p.log2L) {
+                    case 7: launch_fixed<E, H, FAM, LM, SM, TW, HAS_FIX, 7>(tp, grid, p); return;
+                    case 8: launch_fixed<E, H, FAM, LM, SM, TW, HAS_FIX, 8>(tp, grid, p); return;
+                    case 9: launch_fixed<E, H, FAM, LM, SM, TW, HAS_FIX, 9>(tp, grid, p); return;
+                    case 10: launch_fixed<E, H, FAM, LM, SM, TW, HAS_FIX, 10>(tp, grid, p); return;
+                    default: break;
+                }
+            }
+        }
+        launch_kernel(fftk::tile_fft_kernel<T, E, H, FAM, LM, SM, TW, 0>, tp, grid, p);
+    }
+
+    template <int E, int H, int FAM, int LM, int SM, bool TW, bool HAS_FIX, int LOG2L>
+    void launch_fixed(const fftk::TileParams<T>& tp, long long grid, const PassDesc& p) {
+        constexpr int FIX = HAS_FIX ? ((LOG2L << 8) | (13 - (SZ == 16 ? 1 : 0) - LOG2L)) : 0;
+        launch_kernel(fftk::tile_fft_kernel<T, E, H, FAM, LM, SM, TW, FIX>, tp, grid, p);
+    }
+
+    template <class K>
+    void launch_kernel(K kernel, const fftk::TileParams<T>& tp, long long grid, const PassDesc& p) {
         if (grid < 0) {
             // persistent grid: exactly the workgroups that are resident at once (occupancy query: VGPRs, LDS, waves)
             int per_cu = rt->max_blocks_per_cu(kernel, p.nthreads, (size_t)p.smem_bytes);
