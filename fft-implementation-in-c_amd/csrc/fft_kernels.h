@@ -23,6 +23,9 @@ namespace fftk {
 #ifndef FFT_FORCE_OPAQUE
 #define FFT_FORCE_OPAQUE 0
 #endif
+#ifndef FFT_WAVES_PER_SIMD_E4
+#define FFT_WAVES_PER_SIMD_E4 4
+#endif
 enum { LOAD_CCONTIG = 0, LOAD_LCONTIG = 1 };
 enum { STORE_CCONTIG = 0, STORE_LCONTIG = 1 };
 enum { FAM_SR16 = 0, FAM_R4 = 1, FAM_R2 = 2 };
@@ -270,7 +273,7 @@ FFT_DEVICE TileCoord<T> tile_coord(const TileParams<T>& p, long long tile) {
 // FIXED != 0 bakes (log2L << 8 | log2C) into the instantiation: every LDS offset becomes an immediate and the
 // stage loop unrolls (fewer address VGPRs, less integer VALU); FIXED == 0 reads both from the parameters.
 template <typename T, int E, int H, int FAM, int LOADM, int STOREM, bool TWIDDLE, int FIXED>
-FFT_KERNEL void FFT_LAUNCH_BOUNDS2(512, FFT_WAVES_PER_SIMD) tile_fft_kernel(TileParams<T> p) {
+FFT_KERNEL void FFT_LAUNCH_BOUNDS2((E == 4 ? 1024 : 512), (E == 4 ? FFT_WAVES_PER_SIMD_E4 : FFT_WAVES_PER_SIMD)) tile_fft_kernel(TileParams<T> p) {
     constexpr int V = vec16<T>::V;
     constexpr int log2V = Log2<V>::value;
     constexpr int log2E = Log2<E>::value;
