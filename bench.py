@@ -149,13 +149,73 @@ def cpu_baseline(n, dtype, budget_s=12.0):
     for t in th:
         t.join()
     total_pts = float(n) * threads * per_thread
-    return {
+    out = {
         "value": total_pts / wall / 1e9, "unit": "Gpoint/s", "cores": threads, "kind": kind,
         "sample": "%d transforms of N=%d fp64 (%s, the reference's only precision) per thread on %d threads, "
                   "two-tone input, forward; 1-thread best: %.4f Gpoint/s (%.1f ms/transform)"
                   % (per_thread, n, "radix2_dit_fft" if pow2 else "bluestein_fft", threads, n / t_single / 1e9, t_single * 1e3),
         "single_thread_value": n / t_single / 1e9,
     }
+    if pow2:
+        out["fp32_comparators"] = cpu_fp32_comparators(n, threads)
+    return out
+
+
+def cpu_fp32_comparators(n, threads):
+    """The two fp32 CPU comparators the north star names, timing only (a few seconds):
+    - optimizations/simd_fft.c `fft_radix2_sse2` from oracle/_ref/libref_simd.so -- the reference's SSE2 SoA path;
+      its results are numerically wrong (one twiddle for four butterflies), so it is a TIMING
+      comparator only;
+    - the oracle's fp32 interleaved radix-2 DIT with correct twiddles, all cores via OpenMP over the batch index
+      (oracle/liboracle_fast.so, built here with the reference's shipped flags)."""
+    import numpy as np
+    res = {}
+    try:
+        simd = os.path.join(ROOT, "oracle", "_ref", "libref_simd.so")
+        if os.path.exists(simd):
+            lib = C.CDLL(simd)
+            lib.allocate_simd_complex.restype = C.c_void_p
+            lib.allocate_simd_complex.argtypes = [C.c_int]
+            lib.fft_radix2_sse2.argtypes = [C.c_void_p, C.c_int, C.c_int]
+            lib.free_simd_complex.argtypes = [C.c_void_p]
+            h = lib.allocate_simd_complex(n)
+            ptrs = (C.c_void_p * 2).from_address(h)
+            re = np.ctypeslib.as_array((C.c_float * n).from_address(ptrs[0]))
+            im = np.ctypeslib.as_array((C.c_float * n).from_address(ptrs[1]))
+            best = 1e9
+            import oracle_lib as O
+            x0 = O.gen_two_tone(n, 0, 1, np.complex64)[0]
+            for _ in range(5):
+                re[:] = x0.real
+                im[:] = x0.imag
+                t0 = time.perf_counter()
+                lib.fft_radix2_sse2(h, n, -1)
+                best = min(best, time.perf_counter() - t0)
+            lib.free_simd_complex(h)
+            res["reference_simd_fft_sse2_1thread"] = {"value": n / best / 1e9, "unit": "Gpoint/s", "cores": 1,
+                                                       "note": "optimizations/simd_fft.c:143-230, timing only (results wrong in the reference)"}
+    except Exception as e:
+        res["reference_simd_fft_sse2_1thread"] = {"value": None, "note": "failed: %r" % (e,)}
+    try:
+        import subprocess
+        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "liboracle_fast.so"], check=True,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        lib = C.CDLL(os.path.join(ROOT, "oracle", "liboracle_fast.so"))
+        lib.oracle_fft_batch_f32.argtypes = [C.c_void_p, C.c_int, C.c_long, C.c_int]
+        batch = max(threads, 8)
+        import oracle_lib as O
+        x0 = O.gen_two_tone(n, 0, batch, np.complex64)
+        x = x0.copy()
+        lib.oracle_fft_batch_f32(x.ctypes.data, n, batch, -1)
+        x[:] = x0
+        t0 = time.perf_counter()
+        lib.oracle_fft_batch_f32(x.ctypes.data, n, batch, -1)
+        dt = time.perf_counter() - t0
+        res["port_fp32_radix2_dit_all_cores"] = {"value": float(n) * batch / dt / 1e9, "unit": "Gpoint/s", "cores": threads,
+                                                  "note": "oracle_radix2_dit_f32, OpenMP over %d transforms" % batch}
+    except Exception as e:
+        res["port_fp32_radix2_dit_all_cores"] = {"value": None, "note": "failed: %r" % (e,)}
+    return res
 
 
 def main():
