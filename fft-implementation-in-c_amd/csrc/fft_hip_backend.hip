@@ -21,6 +21,16 @@
 #include <vector>
 
 #include "../../include/fft_hip.h"
+#include "fft_kernels.h"
+#include "fft_rows_list.h"
+
+namespace fftk {  // instantiated in fft_rows_o2.hip
+#define FFT_EXTERN(T, E, FAM) \
+    extern template __global__ void tile_fft_kernel<T, E, 1, FAM, LOAD_LCONTIG, STORE_LCONTIG, false, 0>(TileParams<T>);
+FFT_ROWS_LIST(FFT_EXTERN)
+#undef FFT_EXTERN
+}  // namespace fftk
+
 #include "fft_engine.h"
 
 #define HIP_TRY(call, fail)                                                                          \

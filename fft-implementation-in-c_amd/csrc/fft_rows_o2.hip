@@ -1,0 +1,11 @@
+// fft_rows_o2.hip -- explicit instantiation of the single-pass (rows in, rows out) tile kernels; built with -O2
+// (see fft_rows_list.h).  The backend TU declares the same list `extern template`.
+#include "fft_kernels.h"
+#include "fft_rows_list.h"
+
+namespace fftk {
+#define FFT_INSTANTIATE(T, E, FAM) \
+    template __global__ void tile_fft_kernel<T, E, 1, FAM, LOAD_LCONTIG, STORE_LCONTIG, false, 0>(TileParams<T>);
+FFT_ROWS_LIST(FFT_INSTANTIATE)
+#undef FFT_INSTANTIATE
+}  // namespace fftk
