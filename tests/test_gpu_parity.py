@@ -295,3 +295,90 @@ def test_roundtrip_full_size_config3(gpu_lib):
     assert rel(z, x) <= 1e-4
     assert rel(z, x) <= 5e-6
     fwd.destroy(); inv.destroy(); buf.free()
+
+
+def test_additive_api_plan_info_streams_timing(gpu_lib):
+    """Additive entry points of include/fft_hip.h: device count / set_device, plan info, async execute + sync,
+    HIP-event timing, per-pass profiling, raw-pointer execute on a caller-provided stream handle (NULL = own)."""
+    import ctypes as C
+    import fftlib
+    assert gpu_lib.fft_gpu_device_count() >= 1
+    assert gpu_lib.fft_gpu_set_device(0) == 0 and gpu_lib.fft_gpu_set_device(9999) == -1
+    assert gpu_lib.fft_gpu_get_device_hip() == 0
+    n, batch = 1 << 16, 6
+    plan = fftlib.Plan(n, batch, -1, np.complex64)
+    info = plan.info()
+    assert (info.n, info.batch, info.direction, info.precision) == (n, batch, -1, fftlib.PREC_F32)
+    assert info.n_passes == 2 and info.factors[0] * info.factors[1] == n and info.bluestein_m == 0
+    assert info.workspace_bytes >= n * 8
+    x = lcg(n, batch, np.complex64, seed=5)
+    a = fftlib.DeviceBuffer(x.nbytes)
+    b = fftlib.DeviceBuffer(x.nbytes)
+    a.upload(x)
+    assert gpu_lib.fft_gpu_execute_async(plan.handle, a.handle, b.handle) == 0
+    assert gpu_lib.fft_gpu_plan_sync(plan.handle) == 0
+    ref = O.oracle_fft(x.astype(np.complex128), -1, "dit")
+    assert rel(b.download(x.shape, x.dtype), ref) <= 2e-6
+    assert gpu_lib.fft_gpu_plan_set_stream(plan.handle, None) == 0
+    ms = plan.timed(a.ptr, b.ptr, 3)
+    assert ms > 0
+    prof = plan.profile_passes(a.ptr, b.ptr)
+    assert len(prof) == 2 and all(m > 0 and c >= 1 for m, c in prof)
+    assert rel(b.download(x.shape, x.dtype), ref) <= 2e-6
+    # fp32 host-pointer conveniences
+    y = np.zeros_like(x)
+    assert gpu_lib.fft_gpu_dft_1d_batch_f32(x.ctypes.data, y.ctypes.data, n, batch, -1) == 0
+    assert rel(y, ref) <= 2e-6
+    y1 = x[0].copy()
+    assert gpu_lib.fft_gpu_dft_1d_f32(y1.ctypes.data, y1.ctypes.data, n, -1) == 0
+    assert rel(y1, ref[0]) <= 2e-6
+    # undersized buffers are refused, not overrun
+    small = fftlib.DeviceBuffer(64)
+    gpu_lib.fft_gpu_execute(plan.handle, small.handle, small.handle)
+    assert gpu_lib.fft_gpu_copy_h2d_bytes_hip(small.handle, x.ctypes.data, x.nbytes) == -1
+    bi = fftlib.Plan(1000, 2, 1, np.complex128).info()
+    assert bi.bluestein_m == 2048 and bi.direction == 1
+    for buf in (a, b, small):
+        buf.free()
+    plan.destroy()
+
+
+def test_batch_larger_than_one_launch_group(gpu_lib):
+    """The batch is processed in launch groups (FFT_HIP_CHUNK_MB); 40 transforms in groups of 8 must equal the
+    oracle for every transform, in place and out of place, forward and inverse."""
+    import os
+    import fftlib
+    n, batch = 1 << 16, 40
+    x = lcg(n, batch, np.complex64, seed=11)
+    os.environ["FFT_HIP_CHUNK_MB"] = "4"
+    try:
+        plan = fftlib.Plan(n, batch, -1, np.complex64)
+        assert plan.info().chunk_batch == 8
+        plan.destroy()
+        for d, inplace in ((-1, True), (1, False)):
+            y = fftlib.fft(x, d, inplace=inplace)
+            ref = O.oracle_fft(x.astype(np.complex128), d, "dit")
+            for b in range(batch):
+                assert rel(y[b], ref[b]) <= 2e-6, (d, b)
+    finally:
+        del os.environ["FFT_HIP_CHUNK_MB"]
+
+
+@pytest.mark.parametrize("log2n", [21, 22, 24])
+def test_three_pass_sizes(gpu_lib, log2n):
+    """Sizes past the two-pass range use three passes; checked against the analytic two-tone spectrum (fp32)."""
+    import fftlib
+    n = 1 << log2n
+    x = O.gen_two_tone(n, 1, 2, np.complex64)
+    plan = fftlib.Plan(n, 2, -1, np.complex64)
+    assert plan.info().n_passes == 3
+    plan.destroy()
+    y = fftlib.fft(x, -1).astype(np.complex128)
+    for b in range(2):
+        f, g = O.two_tone_bins(n, 1 + b)
+        assert abs(y[b, f] - n) / n < 1e-5 and abs(y[b, g] - n / 2) / n < 1e-5
+        y[b, f] = 0
+        y[b, g] = 0
+        assert np.linalg.norm(y[b]) / (n * np.sqrt(1.25)) < 1e-5
+    back = fftlib.fft(fftlib.fft(x, -1), 1)
+    assert rel(back, x) <= 5e-6
