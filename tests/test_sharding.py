@@ -54,7 +54,7 @@ def test_world_size_2_gloo_sharding(tmp_path):
     env = dict(os.environ, PYTHONPATH=ROOT, MASTER_ADDR="127.0.0.1")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
                           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), str(script)],
-                         capture_output=True, text=True, env=env, timeout=300)
+                         capture_output=True, text=True, env=env, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     import json
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
