@@ -78,6 +78,13 @@ def test_one_wave_radix2_dit_with_shuffles(n):
             assert rel(y, O.oracle_fft(x.astype(np.complex128), d, "dit")) < 1e-6  # the reference's own radix-2 path
 
 
+def test_length_one_is_a_scaled_copy():
+    x = O.gen_lcg(1, 0, 7)
+    for d in (-1, 1):
+        y, _ = E.emu_fft(x, d)
+        assert np.array_equal(y, x)  # n = 1: DFT is the identity, the inverse scale 1/n is 1
+
+
 def test_bluestein_emulated():
     for n in (3, 31, 100, 1009):
         x = O.gen_lcg(n, n, 2)

@@ -297,6 +297,15 @@ def test_roundtrip_full_size_config3(gpu_lib):
     fwd.destroy(); inv.destroy(); buf.free()
 
 
+def test_length_one_and_single_transform(gpu_lib):
+    import fftlib
+    x = lcg(1, 5, np.complex128, seed=2)
+    assert np.array_equal(fftlib.fft(x, -1), x) and np.array_equal(fftlib.fft(x, 1, inplace=False), x)
+    for n in (2, 1024, 1 << 20):  # batch = 1: one (mostly padded) tile per pass
+        x1 = lcg(n, 1, np.complex128, seed=n)[0]
+        assert rel(fftlib.fft(x1, -1), O.oracle_fft(x1, -1, "exact")) <= 1e-14
+
+
 def test_additive_api_plan_info_streams_timing(gpu_lib):
     """Additive entry points of include/fft_hip.h: device count / set_device, plan info, async execute + sync,
     HIP-event timing, per-pass profiling, raw-pointer execute on a caller-provided stream handle (NULL = own)."""
