@@ -391,3 +391,69 @@ def test_three_pass_sizes(gpu_lib, log2n):
         assert np.linalg.norm(y[b]) / (n * np.sqrt(1.25)) < 1e-5
     back = fftlib.fft(fftlib.fft(x, -1), 1)
     assert rel(back, x) <= 5e-6
+
+
+def test_no_device_memory_leak_and_reinit(gpu_lib):
+    """Plans and buffers give their device memory back; cleanup + init cycles keep working."""
+    import ctypes as C
+    import fftlib
+
+    def avail():
+        tot, av = C.c_size_t(), C.c_size_t()
+        gpu_lib.fft_gpu_get_memory_info(C.byref(tot), C.byref(av))
+        return av.value
+
+    x = lcg(4096, 3, np.complex64, seed=1)
+    fftlib.fft(x, -1)
+    before = avail()
+    for i in range(60):
+        for n, dt in ((1 << 16, np.complex64), (1000, np.complex128), (1 << 12, np.complex128)):
+            p = fftlib.Plan(n, 4, -1 if i % 2 else 1, dt)
+            b = fftlib.DeviceBuffer(n * 4 * np.dtype(dt).itemsize)
+            p.execute(b, b)
+            p.destroy()
+            b.free()
+    after = avail()
+    assert before - after < (64 << 20), (before, after)  # nothing accumulates (allow allocator slack)
+    gpu_lib.fft_gpu_cleanup()
+    assert gpu_lib.fft_gpu_get_backend() == 0 and gpu_lib.fft_gpu_get_device_name() == b"No GPU"
+    assert gpu_lib.fft_gpu_alloc(16) is None  # not initialised: refused
+    assert gpu_lib.fft_gpu_init(fftlib.FFT_GPU_AUTO) == 0 and gpu_lib.fft_gpu_get_backend() == fftlib.FFT_GPU_HIP
+    y = fftlib.fft(x, -1)
+    assert rel(y, O.oracle_fft(x.astype(np.complex128), -1, "dit")) <= 2e-6
+
+
+def test_full_size_config4_shard_and_config5(gpu_lib):
+    """BASELINE config 4's per-GPU shard at 8 GPUs (N=262144 fp32, 1024 transforms) against the analytic spectrum
+    of EVERY transform it owns (ranks 0 and 7), and config 5 at full batch (N=1000003 fp64 x 64): forward then
+    inverse returns the input."""
+    import fftlib
+    n, per_gpu = 1 << 18, 1024
+    plan = fftlib.Plan(n, 256, -1, np.complex64)
+    buf = fftlib.DeviceBuffer(n * 256 * 8)
+    for rank in (0, 7):
+        for b0 in range(rank * per_gpu, (rank + 1) * per_gpu, 256):
+            x = O.gen_two_tone(n, b0, 256, np.complex64)
+            buf.upload(x)
+            plan.execute(buf, buf)
+            y = buf.download((256, n), np.complex64)
+            idx = np.arange(256)
+            fg = np.array([O.two_tone_bins(n, b0 + i) for i in range(256)])
+            assert np.max(np.abs(y[idx, fg[:, 0]] - n)) / n < 1e-4
+            assert np.max(np.abs(y[idx, fg[:, 1]] - n / 2)) / n < 1e-4
+            tot = np.linalg.norm(y.astype(np.complex128), axis=1)
+            assert np.max(np.abs(tot / (n * np.sqrt(1.25)) - 1)) < 1e-5  # all energy sits in the two bins
+    plan.destroy()
+    buf.free()
+    n, batch = 1000003, 64
+    x = O.gen_lcg(n, 0, batch)
+    fwd = fftlib.Plan(n, batch, -1, np.complex128)
+    inv = fftlib.Plan(n, batch, 1, np.complex128)
+    d = fftlib.DeviceBuffer(x.nbytes)
+    d.upload(x)
+    fwd.execute(d, d)
+    y = d.download(x.shape, x.dtype)
+    assert rel(y[0], np.fft.fft(x[0])) <= 1e-6 and rel(y[-1], np.fft.fft(x[-1])) <= 1e-6
+    inv.execute(d, d)
+    assert rel(d.download(x.shape, x.dtype), x) <= 1e-6
+    fwd.destroy(); inv.destroy(); d.free()
