@@ -520,6 +520,22 @@ class Pow2Plan {
         if (passes.size() == 2 && ipass == 0) tp.ablate |= (ablate & 16);  // experiment: pass A writes a wrapped (cache-sized) scratch
         if (passes.size() == 2 && ipass == 1) tp.ablate |= (ablate & 32);  // experiment: pass B reads it
         static const int pair16 = getenv("FFT_HIP_PAIR16") ? atoi(getenv("FFT_HIP_PAIR16")) : 0;
+        // column pass with narrow (64-byte) row segments: walk the launch transform-fastest (measured 0.64 -> 0.57 ms
+        // per 128 transforms at L = 1024; wider-segment shapes and row passes prefer the natural order)
+        static const int order_a = getenv("FFT_HIP_ORDER_A") ? atoi(getenv("FFT_HIP_ORDER_A")) : -1;  // column pass; -1 = auto
+        static const int order_b = getenv("FFT_HIP_ORDER_B") ? atoi(getenv("FFT_HIP_ORDER_B")) : 0;  // row pass
+        tp.order_g = 0;
+        tp.tiles_per_b = 1;
+        if (p.n_cols >= 0 && p.n_b_per_transform == 1) {
+            int g = p.loadm == fftk::LOAD_CCONTIG ? order_a : order_b;
+            if (g < 0) {
+                g = 0;
+                if (p.seg_bytes < 128) { g = 1; while (g * 2 <= nb) g *= 2; }
+            }
+            while (g > 1 && (nb % g) != 0) g >>= 1;  // must divide the transforms of this launch
+            tp.order_g = g;
+            tp.tiles_per_b = p.n_o * p.n_ct;
+        }
         tp.pair16 = (pair16 && ((1ll << p.log2C) * SZ < 128)) ? 1 : 0;
         if (p.n_cols < 0) {  // single-pass row kernel: columns are the transforms of the batch
             tp.n_cols = nb;

@@ -73,6 +73,8 @@ struct TileParams {
     long long n_tiles;  // tiles of this launch; a workgroup walks tiles blockIdx, blockIdx + gridDim, ...
     int n_cols;   // columns >= n_cols are padding (read as zero, never stored)
     int inverse;  // 1: inverse transform via the re<->im swap identity
+    int order_g;  // > 1: walk tiles transform-fastest within blocks of order_g transforms (see tile_coord)
+    int tiles_per_b;
     int pair16;   // tile order: pair half-line neighbours on one XCD (see tile_coord)
     int ablate;   // profiling only (FFT_HIP_ABLATE): 1 skip inter-pass twiddle, 2 skip stages
     T scale;      // applied at the store (1/N folded into the last pass)
@@ -250,6 +252,14 @@ template <typename T>
 FFT_DEVICE TileCoord<T> tile_coord(const TileParams<T>& p, long long tile) {
     TileCoord<T> tc;
     unsigned t32 = (unsigned)tile;  // launches never exceed 2^31 tiles
+    if (p.order_g > 1) {
+        // Walk order: within blocks of order_g transforms the TRANSFORM index runs fastest, so the workgroups that
+        // are resident together work on the same column tile of order_g different transforms (measured: the column
+        // pass gains 10 %).  order_g divides the number of transforms of the launch.
+        const unsigned P = (unsigned)p.tiles_per_b, G = (unsigned)p.order_g;
+        const unsigned q = t32 / (G * P), i = t32 - q * (G * P);
+        t32 = (q * G + i % G) * P + i / G;
+    }
     if (p.pair16 && tile < (p.n_tiles & ~15ll)) {
         // Within every 16 consecutive sequence numbers, workgroups g and g + 8 (same XCD under the observed
         // round-robin placement; speed only, never correctness) get column tiles 2k and 2k + 1, i.e. the two
