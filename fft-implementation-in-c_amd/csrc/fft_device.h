@@ -18,8 +18,10 @@ extern thread_local dim3_ threadIdx_;
 extern thread_local dim3_ blockIdx_;
 extern dim3_ blockDim_;
 extern dim3_ gridDim_;
-extern unsigned char* smem_;
+extern thread_local unsigned char* smem_;  // per workgroup (workgroups of a team launch run concurrently)
 void sync_threads();
+long long clock_ticks();
+extern int xcc_skew;  // test hook: workgroup 0 reports its neighbour's XCD, so no launch yields full teams
 unsigned shfl_xor_u32(unsigned v, int mask);
 }  // namespace emu
 #define FFT_KERNEL
@@ -49,6 +51,21 @@ inline T shfl_xor_any(T v, int mask) {
 #define FFT_LAUNCH_BOUNDS2(n, w)
 #define FFT_RESTRICT
 #define FFT_UNROLL
+#define FFT_NOUNROLL
+// ---- team-kernel vocabulary (fft_team.h): the emulation runs the workgroups of a launch concurrently, a "XCD"
+// is blockIdx mod n_teams, every memory operation is sequentially consistent
+#include <sched.h>
+#define FFT_XCC_ID(nteams) ((unsigned)((emu::blockIdx_.x + ((emu::xcc_skew && emu::blockIdx_.x == 0) ? 1u : 0u)) % (unsigned)(nteams)))
+#define FFT_ATOMIC_ADD_AGENT(p, v) __atomic_fetch_add((p), (v), __ATOMIC_SEQ_CST)
+#define FFT_ATOMIC_LOAD_AGENT(p) __atomic_load_n((p), __ATOMIC_SEQ_CST)
+#define FFT_ATOMIC_STORE_AGENT(p, v) __atomic_store_n((p), (v), __ATOMIC_SEQ_CST)
+#define FFT_L2_FLAG_STORE(p, v) __atomic_store_n((p), (v), __ATOMIC_SEQ_CST)
+#define FFT_L2_FLAG_LOAD(p) __atomic_load_n((p), __ATOMIC_SEQ_CST)
+#define FFT_WAIT_VM0() __atomic_thread_fence(__ATOMIC_SEQ_CST)
+#define FFT_SLEEP() sched_yield()
+#define FFT_CLOCK() emu::clock_ticks()
+#define FFT_UNIFORM(v) (v)
+#define FFT_GLDS16(gsrc, ldst, aux) memcpy((ldst), (gsrc), 16)
 #else
 #include <hip/hip_runtime.h>
 #define FFT_KERNEL __global__
@@ -79,6 +96,35 @@ inline T shfl_xor_any(T v, int mask) {
 #define FFT_LAUNCH_BOUNDS2(n, w) __launch_bounds__(n, w)
 #define FFT_RESTRICT __restrict__
 #define FFT_UNROLL _Pragma("unroll")
+#define FFT_NOUNROLL _Pragma("nounroll")
+// ---- team-kernel vocabulary (fft_team.h)
+// The XCD this wave runs on (HW_REG_XCC_ID, bits 3:0).  Workgroups that read the same id share one L2.
+#define FFT_XCC_ID(nteams) ((unsigned)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15u)
+// device-coherent (agent-scope) atomics: team formation and the status word only
+#define FFT_ATOMIC_ADD_AGENT(p, v) __hip_atomic_fetch_add((p), (v), __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT)
+#define FFT_ATOMIC_LOAD_AGENT(p) __hip_atomic_load((p), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)
+#define FFT_ATOMIC_STORE_AGENT(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT)
+// Same-XCD signalling through the XCD's own L2: a PLAIN dword store stays in L2 (write-through L1), an sc1 load
+// bypasses the reader's L1 and is served by that L2.  Valid ONLY between workgroups that read the same XCC id.
+#define FFT_L2_FLAG_STORE(p, v) (*(volatile unsigned*)(p) = (v))
+#define FFT_L2_FLAG_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define FFT_WAIT_VM0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define FFT_SLEEP() __builtin_amdgcn_s_sleep(2)
+#define FFT_CLOCK() ((long long)wall_clock64())
+#define FFT_UNIFORM(v) __builtin_amdgcn_readfirstlane(v)
+// LDS-DMA: 16 bytes per lane from global memory straight into LDS (global_load_lds_dwordx4), no VGPR destination.
+// The 64 lanes of a wave land in 1 KiB CONTIGUOUS LDS bytes starting at the first lane's `ldst`: every call site
+// passes ldst = base + 16 * lane-linear index.  aux: 0 default, 2 nt, 16 sc1 (bypass the vector L1).  Counts in vmcnt.
+#define FFT_GLDS16(gsrc, ldst, aux) fft_glds16<aux>((gsrc), (ldst))
+template <int AUX>
+__device__ __forceinline__ void fft_glds16(const void* gsrc, void* ldst) {
+#if defined(__HIP_DEVICE_COMPILE__)  // the host pass of hipcc must not see the builtin (it silently drops the kernel's stub)
+    __builtin_amdgcn_global_load_lds(gsrc, (__attribute__((address_space(3))) void*)ldst, 16, 0, AUX);
+#else
+    (void)gsrc;
+    (void)ldst;
+#endif
+}
 #endif
 
 namespace fftk {
@@ -126,6 +172,42 @@ struct alignas(16) vec16 {
     static constexpr int V = 16 / (int)sizeof(cpx<T>);
     cpx<T> c[V];
 };
+
+// A window of global memory read with 16-byte loads that bypass the reader's vector L1 (buffer_load_dwordx4 sc1):
+// the team kernel reads what OTHER workgroups of its XCD have just stored, straight from the shared L2.
+#if defined(FFT_EMU)
+struct L2Window {
+    const unsigned char* base;
+};
+FFT_DEVICE L2Window l2_window(const unsigned char* base, unsigned /*bytes*/) {
+    L2Window w;
+    w.base = base;
+    return w;
+}
+template <typename T>
+FFT_DEVICE vec16<T> l2_load16(const L2Window& w, unsigned off) {
+    vec16<T> v;
+    memcpy(&v, w.base + off, 16);
+    return v;
+}
+#else
+struct L2Window {
+    __amdgpu_buffer_rsrc_t rs;
+};
+FFT_DEVICE L2Window l2_window(const unsigned char* base, unsigned bytes) {
+    L2Window w;
+    w.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(base), 0, (int)bytes, 0x00020000);
+    return w;
+}
+template <typename T>
+FFT_DEVICE vec16<T> l2_load16(const L2Window& w, unsigned off) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(w.rs, (int)off, 0, 16 /* sc1 */);
+    vec16<T> v;
+    __builtin_memcpy(&v, &raw, 16);
+    return v;
+}
+#endif
 
 FFT_DEVICE unsigned bitrev32(unsigned v, int log2n) {
     // reverse the low log2n bits (reference include/fft_common.h:59-77, all log2n)

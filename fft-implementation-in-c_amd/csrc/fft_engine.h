@@ -12,6 +12,10 @@
 //   int   max_lds_bytes();   int num_cus();
 //   template <class K> int max_blocks_per_cu(K kernel, int threads, size_t smem);
 //   void  mark(int pass_index);   // profiling hook, called after each pass launch (no-op unless enabled)
+//   void  memset_async(void*, int, size_t);
+//   bool  team_geometry(int& log2TS, int& n_teams, int& nthreads);   // false: no team kernel on this device
+//   long long team_timeout_ticks();
+//   template <class K, class... A> void launch_coresident(K kernel, long long grid, int block, size_t smem, A... args);
 //
 // Scheme (reference optimizations/parallel_fft.c:213-272 is the
 // CPU statement of the same four-step idea):
@@ -33,6 +37,7 @@
 #include <vector>
 
 #include "fft_kernels.h"
+#include "fft_team_list.h"
 
 namespace ffteng {
 
@@ -101,6 +106,22 @@ static void make_twiddle_table(std::vector<cpx<T>>& t, long long period, long lo
     }
 }
 
+// Plan of the team kernel (fft_team.h): one transform per XCD, one HBM round trip.
+template <typename T>
+struct TeamDesc {
+    bool ok = false;
+    int log2L1 = 0, log2L2 = 0, log2CA = 0, log2CB = 0, log2TS = 0, n_teams = 0, NT = 0, nthreads = 0;
+    int data_bytes = 0, tables_elems = 0, smem_bytes = 0;
+    int o_sb1 = 0, o_sa2 = 0, o_sb2 = 0, o_t0 = 0, o_t1 = 0, sa1_bits = 0, sa2_bits = 0, t0_bits = 0;
+    int min_batch = 1;
+    cpx<T>* tables = nullptr;
+    unsigned char* scratch = nullptr;
+    size_t scratch_bytes = 0;
+    unsigned* ctl = nullptr;
+    long long* trace = nullptr;  // profiling only (fft_gpu_plan_team_trace_hip); caller-owned device memory
+    int trace_events = 0;
+};
+
 template <typename T, typename RT>
 class Pow2Plan {
   public:
@@ -118,6 +139,10 @@ class Pow2Plan {
     size_t scratch_bytes = 0;
     std::vector<cpx<T>*> pass_tables;  // one device blob per pass: [sa | sb | t0 | t1 | t2]
     cpx<T>* tw_half = nullptr;  // W_n^k, k < n/2 (RADIX2_GLOBAL)
+    TeamDesc<T> team;           // team.ok: execute() runs the team kernel, with the two-pass plan queued behind it as fallback
+    const unsigned* run_if = nullptr;  // handed to the tile launches of the current execute (fallback mode)
+    int team_pending = 0;        // team launches since the host last read the status word
+    int team_fallbacks = 0;      // consecutive executes that ended in the two-pass fallback
     bool ok = false;
 
     ~Pow2Plan() { destroy(); }
@@ -128,8 +153,130 @@ class Pow2Plan {
         pass_tables.clear();
         if (tw_half) rt->dfree(tw_half);
         if (scratch) rt->dfree(scratch);
+        if (team.tables) rt->dfree(team.tables);
+        if (team.scratch) rt->dfree(team.scratch);
+        if (team.ctl) rt->dfree(team.ctl);
+        team = TeamDesc<T>();
         tw_half = nullptr;
         scratch = nullptr;
+    }
+
+    // ---- team kernel: geometry, tables, the L2-resident transposition windows, the control block
+    void build_team(int batch) {
+        if (const char* e = getenv("FFT_HIP_TEAM")) if (atoi(e) == 0) return;
+        TeamDesc<T> d;
+        if (!rt->team_geometry(d.log2TS, d.n_teams, d.nthreads)) return;
+        const int log2V = ilog2(V);
+        const int log2TE = ilog2(d.nthreads) + 3 + log2V;  // elements of a tile: threads * 8 lane accesses of V elements
+        const int log2NT = log2n - d.log2TS - log2TE;
+        if (log2NT < 0 || log2NT > 2) return;  // the team's registers hold 1, 2 or 4 tiles per workgroup
+        d.NT = 1 << log2NT;
+        d.log2L1 = log2n / 2;
+        d.log2L2 = log2n - d.log2L1;
+        d.log2CA = log2TE - d.log2L1;
+        d.log2CB = log2TE - d.log2L2;
+        if (d.log2L1 < 3 || d.log2CA < log2V || d.log2CB < log2V || d.log2CB > d.log2L1 - 3) return;
+        const long long L1 = 1ll << d.log2L1, L2 = 1ll << d.log2L2;
+        d.data_bytes = 2 * (SZ << log2TE);  // LDS-DMA landing image + work image, one tile each
+        // tables: [sa1 | sb1 | sa2 | sb2 | t0 | t1]
+        d.sa1_bits = (L1 * SZ > 8192) ? (d.log2L1 + 1) / 2 : d.log2L1;
+        d.sa2_bits = (L2 * SZ > 8192) ? (d.log2L2 + 1) / 2 : d.log2L2;
+        d.t0_bits = (log2n + 1) / 2;
+        int ne = 1 << d.sa1_bits;
+        d.o_sb1 = ne; ne += 1 << (d.log2L1 - d.sa1_bits);
+        if (d.log2L2 == d.log2L1) { d.o_sa2 = 0; d.o_sb2 = d.o_sb1; }
+        else { d.o_sa2 = ne; ne += 1 << d.sa2_bits; d.o_sb2 = ne; ne += 1 << (d.log2L2 - d.sa2_bits); }
+        d.o_t0 = ne; ne += 1 << d.t0_bits;
+        d.o_t1 = ne; ne += 1 << (log2n - d.t0_bits);
+        ne = (ne * SZ + 15) / 16 * 16 / SZ;
+        d.tables_elems = ne;
+        d.smem_bytes = d.data_bytes + ne * SZ + 16;
+        if (d.smem_bytes > rt->max_lds_bytes()) return;
+        std::vector<cpx<T>> blob((size_t)ne), part;
+        for (auto& z : blob) { z.re = (T)1; z.im = (T)0; }
+        make_twiddle_table<T>(part, L1, 1ll << d.sa1_bits, 1);
+        std::copy(part.begin(), part.end(), blob.begin());
+        make_twiddle_table<T>(part, L1, 1ll << (d.log2L1 - d.sa1_bits), 1ll << d.sa1_bits);
+        std::copy(part.begin(), part.end(), blob.begin() + d.o_sb1);
+        if (d.log2L2 != d.log2L1) {
+            make_twiddle_table<T>(part, L2, 1ll << d.sa2_bits, 1);
+            std::copy(part.begin(), part.end(), blob.begin() + d.o_sa2);
+            make_twiddle_table<T>(part, L2, 1ll << (d.log2L2 - d.sa2_bits), 1ll << d.sa2_bits);
+            std::copy(part.begin(), part.end(), blob.begin() + d.o_sb2);
+        }
+        const long long n = 1ll << log2n;
+        make_twiddle_table<T>(part, n, 1ll << d.t0_bits, 1);
+        std::copy(part.begin(), part.end(), blob.begin() + d.o_t0);
+        make_twiddle_table<T>(part, n, 1ll << (log2n - d.t0_bits), 1ll << d.t0_bits);
+        std::copy(part.begin(), part.end(), blob.begin() + d.o_t1);
+        d.scratch_bytes = ((size_t)SZ << (log2TE + d.log2TS)) * 2 * (size_t)d.n_teams;
+        d.tables = (cpx<T>*)rt->dmalloc(blob.size() * SZ);
+        d.scratch = (unsigned char*)rt->dmalloc(d.scratch_bytes);
+        d.ctl = (unsigned*)rt->dmalloc(fftk::TEAM_CTL_WORDS * sizeof(unsigned));
+        if (!d.tables || !d.scratch || !d.ctl) {
+            rt->dfree(d.tables); rt->dfree(d.scratch); rt->dfree(d.ctl);
+            return;
+        }
+        rt->h2d(d.tables, blob.data(), blob.size() * SZ);
+        d.min_batch = d.n_teams;  // fewer transforms than teams leave XCDs idle: the two-pass plan spreads one transform over the chip
+        if (const char* e = getenv("FFT_HIP_TEAM_MIN_BATCH")) d.min_batch = atoi(e);
+        (void)batch;
+        d.ok = true;
+        team = d;
+    }
+
+    template <int NT>
+    void launch_team_nt(const fftk::TeamParams<T>& tp) {
+        const long long grid = (long long)team.n_teams << team.log2TS;
+#if defined(FFT_EMU)
+        rt->launch_coresident(fftk::team_fft_kernel<T, NT, 0>, grid, team.nthreads, (size_t)team.smem_bytes, tp);
+#else
+        // the device instantiations have their geometry baked in (fft_team_list.h)
+        constexpr int GEO = fftk::TeamGeo<T, NT>::value;
+        rt->launch_coresident(fftk::team_fft_kernel<T, NT, GEO>, grid, team.nthreads, (size_t)team.smem_bytes, tp);
+#endif
+    }
+
+    bool team_geometry_is_built() const {
+#if defined(FFT_EMU)
+        return true;
+#else
+        const int geo = FFT_TEAM_GEO(team.log2L1, team.log2L2, team.log2CA, team.log2CB, team.log2TS);
+        switch (team.NT) {
+            case 1: return fftk::TeamGeo<T, 1>::value == geo;
+            case 2: return fftk::TeamGeo<T, 2>::value == geo;
+            default: return fftk::TeamGeo<T, 4>::value == geo;
+        }
+#endif
+    }
+
+    void launch_team(const cpx<T>* in, cpx<T>* out, int nb, bool inverse, T scale) {
+        fftk::TeamParams<T> tp;
+        memset(&tp, 0, sizeof(tp));
+        tp.in = in; tp.out = out;
+        tp.tables = team.tables;
+        tp.scratch = team.scratch;
+        tp.ctl = team.ctl;
+        tp.tables_bytes = team.tables_elems * SZ;
+        tp.data_bytes = team.data_bytes;
+        tp.log2L1 = team.log2L1; tp.log2L2 = team.log2L2; tp.log2CA = team.log2CA; tp.log2CB = team.log2CB; tp.log2TS = team.log2TS;
+        tp.n_teams = team.n_teams;
+        tp.nb = nb;
+        tp.inverse = inverse ? 1 : 0;
+        tp.o_sb1 = team.o_sb1; tp.o_sa2 = team.o_sa2; tp.o_sb2 = team.o_sb2; tp.o_t0 = team.o_t0; tp.o_t1 = team.o_t1;
+        tp.sa1_bits = team.sa1_bits; tp.sa2_bits = team.sa2_bits; tp.t0_bits = team.t0_bits;
+        tp.timeout_ticks = rt->team_timeout_ticks();
+        static const int ablate = getenv("FFT_HIP_TEAM_ABLATE") ? atoi(getenv("FFT_HIP_TEAM_ABLATE")) : 0;  // profiling only
+        tp.ablate = ablate;
+        tp.trace = team.trace;
+        tp.trace_events = team.trace_events;
+        tp.scale = scale;
+        rt->memset_async(team.ctl, 0, fftk::TEAM_CTL_WORDS * sizeof(unsigned));
+        switch (team.NT) {
+            case 1: launch_team_nt<1>(tp); break;
+            case 2: launch_team_nt<2>(tp); break;
+            default: launch_team_nt<4>(tp); break;
+        }
     }
 
     // ---- twiddle-table layout of a pass: fills the bit splits and element offsets, returns the element count
@@ -416,6 +563,13 @@ class Pow2Plan {
             scratch = (cpx<T>*)rt->dmalloc(scratch_bytes);
             if (!scratch) return false;
         }
+        if (passes.size() > 1 && algo_ == ALGO_AUTO) {
+            build_team(batch);
+            if (team.ok && !team_geometry_is_built()) {
+                rt->dfree(team.tables); rt->dfree(team.scratch); rt->dfree(team.ctl);
+                team = TeamDesc<T>();
+            }
+        }
         ok = true;
         return true;
     }
@@ -515,6 +669,7 @@ class Pow2Plan {
         tp.in_blk_bits = p.in_blk_bits; tp.in_blk_stride = p.in_blk_stride;
         tp.inverse = inverse ? 1 : 0;
         tp.scale = scale;
+        tp.run_if = run_if;
         static const int ablate = getenv("FFT_HIP_ABLATE") ? atoi(getenv("FFT_HIP_ABLATE")) : 0;  // profiling only
         tp.ablate = ablate & ~48;
         if (passes.size() == 2 && ipass == 0) tp.ablate |= (ablate & 16);  // experiment: pass A writes a wrapped (cache-sized) scratch
@@ -596,24 +751,36 @@ class Pow2Plan {
             rt->mark(0);
             return;
         }
+        // Team kernel first; the multi-pass plan below is then queued as its fallback: its launches read the team
+        // kernel's status word and return at once unless the teams could not be formed (nothing touched yet).
+        run_if = nullptr;
+        int mark0 = 0;
+        if (team.ok && nb >= team.min_batch) {
+            launch_team(in, out, nb, inverse, scale);
+            team_pending++;
+            rt->mark(0);
+            run_if = team.ctl + fftk::TEAM_CTL_STATUS;
+            mark0 = 1;
+        }
         for (int b0 = 0; b0 < nb; b0 += chunk) {
             const int cb = (nb - b0) < chunk ? (nb - b0) : chunk;
             const cpx<T>* src = in + (size_t)b0 * (size_t)n;
             cpx<T>* dst = out + (size_t)b0 * (size_t)n;
             if (passes.size() == 2) {
                 launch_pass(0, src, scratch, cb, inverse, (T)1);
-                rt->mark(0);
+                rt->mark(mark0 + 0);
                 launch_pass(1, scratch, dst, cb, inverse, scale);
-                rt->mark(1);
+                rt->mark(mark0 + 1);
             } else {
                 launch_pass(0, src, scratch, cb, inverse, (T)1);
-                rt->mark(0);
+                rt->mark(mark0 + 0);
                 launch_pass(1, scratch, scratch, cb, inverse, (T)1);
-                rt->mark(1);
+                rt->mark(mark0 + 1);
                 launch_pass(2, scratch, dst, cb, inverse, scale);
-                rt->mark(2);
+                rt->mark(mark0 + 2);
             }
         }
+        run_if = nullptr;
     }
 };
 

@@ -98,6 +98,22 @@ struct HipRT {
         marks.push_back(std::make_pair(pass_index, e));
     }
 
+    void memset_async(void* p, int v, size_t bytes) { (void)hipMemsetAsync(p, v, bytes, stream); }
+    // Team kernel (fft_team.h): built for the MI355X shape, 8 XCDs x 32 CUs, one 512-thread workgroup per CU.  The
+    // kernel verifies the placement itself (HW_REG_XCC_ID); this only says whether the shape can exist here.
+    bool team_geometry(int& log2TS, int& n_teams, int& nthreads) {
+        if (cus != 256) return false;
+        log2TS = 5;
+        n_teams = 8;
+        nthreads = 512;
+        return true;
+    }
+    long long team_timeout_ticks() { return 20000000ll; }  // 0.2 s of the 100 MHz wall clock
+    template <class K, class... A>
+    void launch_coresident(K kernel, long long grid, int block, size_t smem, A... args) {
+        launch(kernel, grid, block, smem, args...);  // LDS footprint > 80 KiB: one workgroup per CU, grid == CUs
+    }
+
     template <class K, class... A>
     void launch(K kernel, long long grid, int block, size_t smem, A... args) {
         const void* key = reinterpret_cast<const void*>(kernel);
@@ -162,6 +178,40 @@ struct DeviceGuard {
         if (switched) (void)hipSetDevice(prev);
     }
 };
+
+// After a stream sync: what did the last team kernel (fft_team.h) report?  0 done by the team kernel, 1 teams could
+// not be formed and the two-pass fallback did the work, 2 a team barrier timed out (results invalid), -1 no team
+// kernel in this plan / nothing launched.  Three fallbacks in a row switch the team kernel off for the plan.
+template <class Core>
+int team_status_of(Core* core) {
+    if (!core || !core->team.ok || !core->team_pending) return -1;
+    unsigned st = 0;
+    if (hipMemcpy(&st, core->team.ctl + fftk::TEAM_CTL_STATUS, sizeof(st), hipMemcpyDeviceToHost) != hipSuccess) {
+        (void)hipGetLastError();
+        return -1;
+    }
+    core->team_pending = 0;
+    if (st == fftk::TEAM_STATUS_NO_TEAMS) {
+        if (++core->team_fallbacks >= 3) {
+            fprintf(stderr, "fft_hip: the team kernel could not form its XCD teams three times in a row; this plan "
+                            "continues with the two-pass schedule\n");
+            core->team.ok = false;
+        }
+    } else {
+        core->team_fallbacks = 0;
+    }
+    if (st == fftk::TEAM_STATUS_TIMEOUT) fprintf(stderr, "fft_hip: team kernel barrier timed out -- results of the last execute are invalid\n");
+    return (int)st;
+}
+
+int plan_team_status(fft_gpu_plan* p) {
+    if (!p) return -1;
+    if (p->p32) return team_status_of(p->p32);
+    if (p->p64) return team_status_of(p->p64);
+    if (p->b32) return team_status_of(&p->b32->core);
+    if (p->b64) return team_status_of(&p->b64->core);
+    return -1;
+}
 
 int plan_enqueue(fft_gpu_plan* p, const void* d_in, void* d_out) {
     if (!p || !d_in || !d_out) return -1;
@@ -394,7 +444,29 @@ int fft_gpu_plan_sync_hip(fft_gpu_plan_t p) {
     if (!p) return -1;
     DeviceGuard guard(p->device);
     HIP_TRY(hipStreamSynchronize(p->rt.stream), return -1);
-    return 0;
+    return plan_team_status(p) == (int)fftk::TEAM_STATUS_TIMEOUT ? -1 : 0;
+}
+
+// Profiling: every workgroup of the team kernel logs its 100 MHz wall clock at its first `events` timeline events
+// into d_trace[workgroup * events + i] (device memory of 256 * events * 8 bytes, owned by the caller).  NULL = off.
+int fft_gpu_plan_team_trace_hip(fft_gpu_plan_t p, void* d_trace, int events) {
+    if (!p) return -1;
+    auto set = [&](auto* core) {
+        if (!core || !core->team.ok) return -1;
+        core->team.trace = (long long*)d_trace;
+        core->team.trace_events = d_trace ? events : 0;
+        return 0;
+    };
+    if (p->p32) return set(p->p32);
+    if (p->p64) return set(p->p64);
+    return -1;
+}
+
+int fft_gpu_plan_team_status_hip(fft_gpu_plan_t p) {
+    if (!p) return -1;
+    DeviceGuard guard(p->device);
+    HIP_TRY(hipStreamSynchronize(p->rt.stream), return -1);
+    return plan_team_status(p);
 }
 
 void fft_gpu_execute_hip(fft_gpu_plan_t p, fft_gpu_memory_t in, fft_gpu_memory_t out, fft_direction /*ignored*/) {
@@ -421,6 +493,7 @@ int fft_gpu_execute_timed_hip(fft_gpu_plan_t p, const void* d_in, void* d_out, i
     HIP_TRY(hipEventRecord(p->ev1, p->rt.stream), return -1);
     HIP_TRY(hipEventSynchronize(p->ev1), return -1);
     HIP_TRY(hipEventElapsedTime(elapsed_ms, p->ev0, p->ev1), return -1);
+    if (plan_team_status(p) == (int)fftk::TEAM_STATUS_TIMEOUT) return -1;
     return 0;
 }
 
@@ -464,6 +537,8 @@ int fft_gpu_plan_info_hip(fft_gpu_plan_t p, fft_gpu_plan_info_t* info) {
     auto fill = [&](auto* core) {
         info->algo = core->algo;
         info->chunk_batch = core->chunk;
+        info->team_tiles = core->team.ok ? core->team.NT : 0;
+        if (core->team.ok) info->workspace_bytes += core->team.scratch_bytes;
         info->workspace_bytes += core->scratch_bytes;
         if (core->algo == ffteng::ALGO_RADIX2_SHFL) {
             info->n_passes = 1;

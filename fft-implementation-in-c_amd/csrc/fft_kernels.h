@@ -77,6 +77,9 @@ struct TileParams {
     int tiles_per_b;
     int pair16;   // tile order: pair half-line neighbours on one XCD (see tile_coord)
     int ablate;   // profiling only (FFT_HIP_ABLATE): 1 skip inter-pass twiddle, 2 skip stages
+    // not NULL: this launch is the fallback behind a team kernel (fft_team.h) and runs only if that kernel left
+    // TEAM_STATUS_NO_TEAMS (1) in the word, i.e. gave up before touching anything
+    const unsigned* run_if;
     T scale;      // applied at the store (1/N folded into the last pass)
 };
 
@@ -114,9 +117,28 @@ struct StageTw {
 // After the last stage slot e holds frequency K = r + TPC*e -- the same shape
 // the inputs were loaded in, so a c-contiguous store needs no further exchange.
 // ---------------------------------------------------------------------------
+// General form: the inputs are read from the image at `smem_rd`, the outputs written to the image at `smem`
+// (the same image in the tile kernels; the team kernel's first stage reads the LDS-DMA landing buffer and writes
+// the work buffer).  `after_read` runs once every wave has finished reading `smem_rd` (not called when first).
+struct StageNoHook {
+    FFT_DEVICE void operator()() const {}
+};
+template <typename T, int E, int R, int V, int H, class Hook>
+FFT_DEVICE void stockham_stage_rw(cpx<T> (&x)[H][E][V], const unsigned char* smem_rd, unsigned char* smem, int group_bytes,
+                                  const StageTw<T>& tw, int r, int j, int log2J, int log2TPC, int& log2Lprev, int& log2P,
+                                  bool first, bool last, Hook&& after_read, bool swap_in = false);
+
 template <typename T, int E, int R, int V, int H>
 FFT_DEVICE void stockham_stage(cpx<T> (&x)[H][E][V], unsigned char* smem, int group_bytes, const StageTw<T>& tw, int r,
                                int j, int log2J, int log2TPC, int& log2Lprev, int& log2P, bool first, bool last) {
+    stockham_stage_rw<T, E, R, V, H>(x, smem, smem, group_bytes, tw, r, j, log2J, log2TPC, log2Lprev, log2P, first, last,
+                                     StageNoHook());
+}
+
+template <typename T, int E, int R, int V, int H, class Hook>
+FFT_DEVICE void stockham_stage_rw(cpx<T> (&x)[H][E][V], const unsigned char* smem_rd, unsigned char* smem, int group_bytes,
+                                  const StageTw<T>& tw, int r, int j, int log2J, int log2TPC, int& log2Lprev, int& log2P,
+                                  bool first, bool last, Hook&& after_read, bool swap_in) {
     // The H column groups of a tile go through every phase TOGETHER (own LDS region each, shared barriers):
     // twice the independent work between two barriers, half the barriers per byte.
     constexpr int G = E / R;
@@ -127,7 +149,7 @@ FFT_DEVICE void stockham_stage(cpx<T> (&x)[H][E][V], unsigned char* smem, int gr
     if (!first) {
         FFT_UNROLL
         for (int h = 0; h < H; h++) {
-            const vec16<T>* data = reinterpret_cast<const vec16<T>*>(smem + h * group_bytes);
+            const vec16<T>* data = reinterpret_cast<const vec16<T>*>(smem_rd + h * group_bytes);
             FFT_UNROLL
             for (int m = 0; m < G; m++) {
                 const int u = r + (m << log2TPC);
@@ -138,7 +160,7 @@ FFT_DEVICE void stockham_stage(cpx<T> (&x)[H][E][V], unsigned char* smem, int gr
                 for (int a = 0; a < R; a++) {
                     vec16<T> v = data[((base + (a << log2Li)) << log2J) + j];
                     FFT_UNROLL
-                    for (int vv = 0; vv < V; vv++) x[h][m + G * a][vv] = v.c[vv];
+                    for (int vv = 0; vv < V; vv++) x[h][m + G * a][vv] = swap_in ? cswap(v.c[vv]) : v.c[vv];
                 }
             }
         }
@@ -176,7 +198,10 @@ FFT_DEVICE void stockham_stage(cpx<T> (&x)[H][E][V], unsigned char* smem, int gr
                 }
             }
         }
-        if (!first) FFT_SYNC_LDS();  // everyone has finished reading the previous exchange
+        if (!first) {
+            FFT_SYNC_LDS();  // everyone has finished reading the previous exchange
+            after_read();
+        }
         FFT_UNROLL
         for (int h = 0; h < H; h++) {
             vec16<T>* data = reinterpret_cast<vec16<T>*>(smem + h * group_bytes);
@@ -290,6 +315,7 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2((E == 4 ? 1024 : 512), (E == 4 ? FFT_WAVES_PE
     constexpr int log2H = Log2<H>::value;
     constexpr int SZ = (int)sizeof(cpx<T>);
     FFT_DYN_SMEM(smem);
+    if (p.run_if && *p.run_if != 1u) return;
 
     const int tid_invariant = FFT_TID;
     const int tid = tid_invariant;

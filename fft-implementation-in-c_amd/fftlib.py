@@ -26,7 +26,8 @@ FFT_PREFER_GPU = 1 << 9
 class PlanInfo(C.Structure):
     _fields_ = [("n", C.c_int), ("batch", C.c_int), ("direction", C.c_int), ("precision", C.c_int),
                 ("algo", C.c_int), ("device", C.c_int), ("bluestein_m", C.c_int), ("n_passes", C.c_int),
-                ("factors", C.c_int * 4), ("chunk_batch", C.c_int), ("workspace_bytes", C.c_size_t)]
+                ("factors", C.c_int * 4), ("chunk_batch", C.c_int), ("workspace_bytes", C.c_size_t),
+                ("team_tiles", C.c_int)]
 
 
 # every symbol include/*.h declares, with its ctypes signature
@@ -56,6 +57,7 @@ SIGNATURES = {
     "fft_gpu_memory_bytes_hip": (_sz, [_vp]), "fft_gpu_plan_1d_ex_hip": (_vp, [_i, _i, _i, _i, _i]),
     "fft_gpu_plan_info_hip": (_i, [_vp, C.POINTER(PlanInfo)]), "fft_gpu_plan_set_stream_hip": (_i, [_vp, _vp]),
     "fft_gpu_execute_ptr_hip": (_i, [_vp, _vp, _vp]), "fft_gpu_plan_sync_hip": (_i, [_vp]),
+    "fft_gpu_plan_team_status_hip": (_i, [_vp]), "fft_gpu_plan_team_trace_hip": (_i, [_vp, _vp, _i]),
     "fft_gpu_execute_timed_hip": (_i, [_vp, _vp, _vp, _i, C.POINTER(C.c_float)]),
     "fft_gpu_dft_1d_batch_hip": (_i, [_vp, _vp, _i, _i, _i, _i]),
     "fft_gpu_profile_passes_hip": (_i, [_vp, _vp, _vp, C.POINTER(C.c_float), C.POINTER(C.c_int), _i]),
@@ -178,6 +180,10 @@ class Plan:
 
     def sync(self):
         self.lib.fft_gpu_plan_sync(self.handle)
+
+    def team_status(self):
+        """0 team kernel did the last execute, 1 its fallback did, 2 barrier timeout, -1 no team kernel / nothing new."""
+        return self.lib.fft_gpu_plan_team_status_hip(self.handle)
 
     def timed(self, d_in, d_out, iters):
         ms = C.c_float()

@@ -82,6 +82,9 @@ typedef struct {
     int factors[4];     /* length of the LDS-resident sub-transform of each pass */
     int chunk_batch;    /* transforms processed per launch group (Infinity-Cache blocking) */
     size_t workspace_bytes;
+    int team_tiles;     /* 0: multi-pass schedule only.  1/2/4: the plan runs the one-round-trip team kernel (a whole
+                           transform per XCD, this many 64 KiB tiles per workgroup); the multi-pass schedule
+                           described by n_passes/factors is queued behind it as its fallback */
 } fft_gpu_plan_info_t;
 
 /* backend-level additive entry points */
@@ -98,6 +101,13 @@ int fft_gpu_plan_info_hip(fft_gpu_plan_t plan, fft_gpu_plan_info_t* info);
 int fft_gpu_plan_set_stream_hip(fft_gpu_plan_t plan, void* hip_stream); /* NULL = the plan's own stream */
 int fft_gpu_execute_ptr_hip(fft_gpu_plan_t plan, const void* d_in, void* d_out); /* async on the plan's stream */
 int fft_gpu_plan_sync_hip(fft_gpu_plan_t plan);
+/* syncs the plan's stream, then: 0 the last execute was done by the team kernel, 1 its XCD teams could not be
+ * formed and the multi-pass fallback did the work, 2 a team barrier timed out (results invalid; plan_sync returns -1
+ * too), -1 the plan has no team kernel or nothing was launched since the last query */
+int fft_gpu_plan_team_status_hip(fft_gpu_plan_t plan);
+/* profiling: every workgroup of the team kernel logs its 100 MHz clock at its first `events` timeline events into
+ * d_trace[workgroup * events + i] (256 * events * 8 bytes of device memory owned by the caller); NULL switches it off */
+int fft_gpu_plan_team_trace_hip(fft_gpu_plan_t plan, void* d_trace, int events);
 /* `iters` back-to-back executes bracketed by hipEvents recorded on the plan's stream */
 int fft_gpu_execute_timed_hip(fft_gpu_plan_t plan, const void* d_in, void* d_out, int iters, float* elapsed_ms);
 /* one execute with a HIP event after every pass launch: per-pass device milliseconds and launch counts */

@@ -8,10 +8,17 @@ thread_local dim3_ threadIdx_;
 thread_local dim3_ blockIdx_;
 dim3_ blockDim_;
 dim3_ gridDim_;
-unsigned char* smem_ = nullptr;
-static pthread_barrier_t g_barrier;
+thread_local unsigned char* smem_ = nullptr;
+int xcc_skew = 0;
+static thread_local pthread_barrier_t* g_barrier = nullptr;  // the barrier of this thread's workgroup
 
-void sync_threads() { pthread_barrier_wait(&g_barrier); }
+void sync_threads() { pthread_barrier_wait(g_barrier); }
+
+long long clock_ticks() {  // 100 MHz, like the device's wall clock
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (long long)ts.tv_sec * 100000000ll + ts.tv_nsec / 10;
+}
 
 unsigned shfl_xor_u32(unsigned v, int mask) {
     static unsigned xchg[1024];
@@ -26,30 +33,60 @@ void Runtime::run_grid(long long grid, int block, size_t smem, const std::functi
     blockDim_ = {(unsigned)block, 1, 1};
     gridDim_ = {(unsigned)grid, 1, 1};
     std::vector<unsigned char> lds(smem + 64, 0xFF);  // NaN-filled: reads of unwritten LDS poison the result
-    smem_ = lds.data() + ((16 - ((uintptr_t)lds.data() & 15)) & 15);
-    pthread_barrier_init(&g_barrier, nullptr, (unsigned)block);
+    unsigned char* lds_base = lds.data() + ((16 - ((uintptr_t)lds.data() & 15)) & 15);
+    pthread_barrier_t barrier;
+    pthread_barrier_init(&barrier, nullptr, (unsigned)block);
     std::vector<std::thread> th;
     th.reserve(block);
     for (int t = 0; t < block; t++) {
         th.emplace_back([&, t]() {
             threadIdx_ = {(unsigned)t, 0, 0};
+            smem_ = lds_base;
+            g_barrier = &barrier;
             for (long long b = 0; b < grid; b++) {
                 blockIdx_ = {(unsigned)b, 0, 0};
                 body();
-                pthread_barrier_wait(&g_barrier);  // next block reuses the LDS image
+                pthread_barrier_wait(&barrier);  // next block reuses the LDS image
             }
         });
     }
     for (auto& x : th) x.join();
-    pthread_barrier_destroy(&g_barrier);
-    smem_ = nullptr;
+    pthread_barrier_destroy(&barrier);
+}
+
+// Every workgroup of the launch runs at the same time (own LDS image, own barrier): what a kernel with
+// inter-workgroup barriers (fft_team.h) needs.  grid * block host threads.
+void Runtime::run_grid_coresident(long long grid, int block, size_t smem, const std::function<void()>& body) {
+    blockDim_ = {(unsigned)block, 1, 1};
+    gridDim_ = {(unsigned)grid, 1, 1};
+    std::vector<std::vector<unsigned char>> lds((size_t)grid, std::vector<unsigned char>(smem + 64, 0xFF));
+    std::vector<pthread_barrier_t> barriers((size_t)grid);
+    for (auto& b : barriers) pthread_barrier_init(&b, nullptr, (unsigned)block);
+    std::vector<std::thread> th;
+    th.reserve((size_t)grid * block);
+    for (long long b = 0; b < grid; b++) {
+        for (int t = 0; t < block; t++) {
+            th.emplace_back([&, b, t]() {
+                threadIdx_ = {(unsigned)t, 0, 0};
+                blockIdx_ = {(unsigned)b, 0, 0};
+                unsigned char* base = lds[(size_t)b].data();
+                smem_ = base + ((16 - ((uintptr_t)base & 15)) & 15);
+                g_barrier = &barriers[(size_t)b];
+                body();
+            });
+        }
+    }
+    for (auto& x : th) x.join();
+    for (auto& b : barriers) pthread_barrier_destroy(&b);
 }
 }  // namespace emu
 
 template <typename T>
-static int run(const void* in, void* out, int n, int batch, int dir, int algo, int lds_budget, int* info) {
+static int run(const void* in, void* out, int n, int batch, int dir, int algo, int lds_budget, int* info, int team = 0) {
     emu::Runtime rt;
     if (lds_budget > 0) rt.lds_budget = lds_budget;
+    rt.team_mode = team;
+    emu::xcc_skew = rt.team_grid_skew();
     using C = fftk::cpx<T>;
     if (n >= 1 && (n & (n - 1)) == 0) {
         ffteng::Pow2Plan<T, emu::Runtime> plan;
@@ -61,6 +98,7 @@ static int run(const void* in, void* out, int n, int batch, int dir, int algo, i
                 info[2 + 2 * i] = plan.passes[i].log2C;
             }
             info[7] = plan.chunk;
+            if (plan.team.ok) info[0] += 100 * plan.team.NT;  // 100*NT + passes: the team kernel is planned
         }
         plan.execute((const C*)in, (C*)out, batch, dir > 0);
     } else {
@@ -76,6 +114,13 @@ extern "C" int emu_fft(const void* in, void* out, int n, int batch, int dir, int
                        int* info) {
     return prec == 1 ? run<float>(in, out, n, batch, dir, algo, lds_budget, info)
                      : run<double>(in, out, n, batch, dir, algo, lds_budget, info);
+}
+
+// team kernel (fft_team.h) with a small geometry: team_mode = 1 + log2TS | n_teams << 4 | threads << 8 | fail << 20
+extern "C" int emu_fft_team(const void* in, void* out, int n, int batch, int dir, int prec, int lds_budget, int team_mode,
+                            int* info) {
+    return prec == 1 ? run<float>(in, out, n, batch, dir, 0, lds_budget, info, team_mode)
+                     : run<double>(in, out, n, batch, dir, 0, lds_budget, info, team_mode);
 }
 
 extern "C" int emu_bitrev(const void* in, void* out, int n, int batch, int prec) {

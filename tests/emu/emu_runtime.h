@@ -23,6 +23,19 @@ struct Runtime {
     int cus = 3;  // few "CUs" so that every workgroup walks several tiles (exercises the persistent loop + prefetch)
     int num_cus() { return cus; }
     void mark(int) {}
+    void memset_async(void* p, int v, size_t bytes) { memset(p, v, bytes); }
+    // team kernel geometry for the emulation (0 = no team kernel): bits 0-3 log2TS + 1, 4-7 teams, 8-19 threads,
+    // bit 20: pretend the placement is wrong (one "XCD" gets a workgroup too many) to exercise the fallback
+    int team_mode = 0;
+    bool team_geometry(int& log2TS, int& n_teams, int& nthreads) {
+        if (!team_mode) return false;
+        log2TS = (team_mode & 15) - 1;
+        n_teams = (team_mode >> 4) & 15;
+        nthreads = (team_mode >> 8) & 4095;
+        return true;
+    }
+    long long team_timeout_ticks() { return 60ll * 100000000ll; }
+    int team_grid_skew() { return (team_mode >> 20) & 1; }
     template <class K>
     int max_blocks_per_cu(K, int, size_t) { return 1; }
     long long launches = 0;
@@ -32,7 +45,13 @@ struct Runtime {
         launches++;
         run_grid(grid, block, smem, [&]() { kernel(args...); });
     }
+    template <class K, class... A>
+    void launch_coresident(K kernel, long long grid, int block, size_t smem, A... args) {
+        launches++;
+        run_grid_coresident(grid, block, smem, [&]() { kernel(args...); });
+    }
     static void run_grid(long long grid, int block, size_t smem, const std::function<void()>& body);
+    static void run_grid_coresident(long long grid, int block, size_t smem, const std::function<void()>& body);
 };
 
 }  // namespace emu

@@ -31,6 +31,9 @@ def lib():
         _lib.emu_fft.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.POINTER(C.c_int)]
         _lib.emu_fft.restype = C.c_int
+        _lib.emu_fft_team.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.POINTER(C.c_int)]
+        _lib.emu_fft_team.restype = C.c_int
         _lib.emu_bitrev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
     return _lib
 
@@ -49,4 +52,24 @@ def emu_fft(x, direction=-1, algo=0, lds_budget=0, inplace=False):
         rc = lib().emu_fft(x.ctypes.data, out.ctypes.data, n, batch, direction, prec, algo, lds_budget, info)
     if rc != 0:
         raise RuntimeError("emu_fft failed")
+    return out, list(info)
+
+
+def emu_fft_team(x, direction=-1, log2ts=2, n_teams=2, threads=16, lds_budget=0, inplace=False, skew=False):
+    """The team kernel (fft_team.h) with a small geometry: n_teams "XCDs" of 2^log2ts workgroups of `threads`
+    threads, all running concurrently.  info[0] = 100*NT + passes when the team kernel was planned.
+    skew=True makes workgroup 0 report the wrong XCD: the kernel must give up and the two-pass fallback run."""
+    x = np.ascontiguousarray(x)
+    prec = 1 if x.dtype == np.complex64 else 0
+    batch, n = x.shape
+    info = (C.c_int * 8)()
+    mode = (log2ts + 1) | (n_teams << 4) | (threads << 8) | ((1 << 20) if skew else 0)
+    if inplace:
+        out = x.copy()
+        rc = lib().emu_fft_team(out.ctypes.data, out.ctypes.data, n, batch, direction, prec, lds_budget, mode, info)
+    else:
+        out = np.full_like(x, np.nan)
+        rc = lib().emu_fft_team(x.ctypes.data, out.ctypes.data, n, batch, direction, prec, lds_budget, mode, info)
+    if rc != 0:
+        raise RuntimeError("emu_fft_team failed")
     return out, list(info)
