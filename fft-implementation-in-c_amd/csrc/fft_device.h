@@ -66,6 +66,10 @@ inline T shfl_xor_any(T v, int mask) {
 #define FFT_CLOCK() emu::clock_ticks()
 #define FFT_UNIFORM(v) (v)
 #define FFT_GLDS16(gsrc, ldst, aux) memcpy((ldst), (gsrc), 16)
+#define FFT_LDS_ADDR(ptr) 0u
+#define FFT_DMA16(gsrc, lds_base_ptr, lds_base_addr, off) memcpy((lds_base_ptr) + (off), (gsrc), 16)
+#define FFT_DMA16_L2(gsrc, lds_base_ptr, lds_base_addr, off) memcpy((lds_base_ptr) + (off), (gsrc), 16)
+#define FFT_WAIT_VM_LE8() __atomic_thread_fence(__ATOMIC_SEQ_CST)
 #else
 #include <hip/hip_runtime.h>
 #define FFT_KERNEL __global__
@@ -115,6 +119,33 @@ inline T shfl_xor_any(T v, int mask) {
 // LDS-DMA: 16 bytes per lane from global memory straight into LDS (global_load_lds_dwordx4), no VGPR destination.
 // The 64 lanes of a wave land in 1 KiB CONTIGUOUS LDS bytes starting at the first lane's `ldst`: every call site
 // passes ldst = base + 16 * lane-linear index.  aux: 0 default, 2 nt, 16 sc1 (bypass the vector L1).  Counts in vmcnt.
+// Hand-issued LDS-DMA (inline asm): hipcc does not see it, so it neither counts it in its own s_waitcnt bookkeeping
+// (its waits only get stricter: vmcnt is in order) nor drains it in front of LDS reads that "may alias" -- the kernel
+// waits for its DMA itself (FFT_WAIT_VM0 / FFT_WAIT_VM_LE8 + barrier) before anybody reads the landing image.
+//   FFT_DMA16     from HBM, default cache policy        FFT_DMA16_L2  sc1: served by the XCD's L2, never the vector L1
+//   FFT_LDS_ADDR  the 32-bit LDS byte address of a __shared__ pointer (taken once per kernel)
+// `off` is the byte offset of THIS lane's 16 bytes from the image base; the wave's first lane gives M0.
+#define FFT_LDS_ADDR(ptr) ((unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(ptr))
+#define FFT_DMA16(gsrc, lds_base_ptr, lds_base_addr, off) fft_dma16<0>((gsrc), (lds_base_addr) + (unsigned)(off))
+#define FFT_DMA16_L2(gsrc, lds_base_ptr, lds_base_addr, off) fft_dma16<1>((gsrc), (lds_base_addr) + (unsigned)(off))
+#define FFT_WAIT_VM_LE8() asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
+template <int SC1>
+__device__ __forceinline__ void fft_dma16(const void* gsrc, unsigned lane_lds_addr) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // M0 = LDS byte address of the wave's first lane; the hardware adds 16 * lane
+    const unsigned lds_addr = __builtin_amdgcn_readfirstlane(lane_lds_addr);
+    unsigned saved_m0;
+    if (SC1)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off sc1\n\ts_mov_b32 m0, %0"
+                     : "=&s"(saved_m0) : "v"(gsrc), "s"(lds_addr) : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(saved_m0) : "v"(gsrc), "s"(lds_addr) : "memory");
+#else
+    (void)gsrc;
+    (void)lane_lds_addr;
+#endif
+}
 #define FFT_GLDS16(gsrc, ldst, aux) fft_glds16<aux>((gsrc), (ldst))
 template <int AUX>
 __device__ __forceinline__ void fft_glds16(const void* gsrc, void* ldst) {
@@ -170,6 +201,12 @@ FFT_DEVICE cpx<T> cswap(cpx<T> a) { return mk<T>(a.im, a.re); }
 template <typename T>
 struct alignas(16) vec16 {
     static constexpr int V = 16 / (int)sizeof(cpx<T>);
+    cpx<T> c[V];
+};
+
+// V adjacent complex values moved by ONE LDS access of a Stockham stage (V * sizeof(cpx<T>) bytes: 8 or 16).
+template <typename T, int V>
+struct alignas(V * sizeof(cpx<T>)) lvec {
     cpx<T> c[V];
 };
 

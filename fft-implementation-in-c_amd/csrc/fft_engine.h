@@ -172,10 +172,12 @@ class Pow2Plan {
         if (log2NT < 0 || log2NT > 2) return;  // the team's registers hold 1, 2 or 4 tiles per workgroup
         d.NT = 1 << log2NT;
         d.log2L1 = log2n / 2;
+        if (const char* e = getenv("FFT_HIP_TEAM_L1")) d.log2L1 = atoi(e);  // experiments / tests: force the split
         d.log2L2 = log2n - d.log2L1;
         d.log2CA = log2TE - d.log2L1;
         d.log2CB = log2TE - d.log2L2;
-        if (d.log2L1 < 3 || d.log2CA < log2V || d.log2CB < log2V || d.log2CB > d.log2L1 - 3) return;
+        // a thread holds 8 * V elements of one column; fp32 pairs the lanes of adjacent rows for its 16-byte stores
+        if (d.log2L1 < 3 + log2V + log2V || d.log2L2 < 3 + log2V || d.log2CA < log2V || d.log2CB < log2V || d.log2CA > 5) return;
         const long long L1 = 1ll << d.log2L1, L2 = 1ll << d.log2L2;
         d.data_bytes = 2 * (SZ << log2TE);  // LDS-DMA landing image + work image, one tile each
         // tables: [sa1 | sb1 | sa2 | sb2 | t0 | t1]
@@ -268,6 +270,12 @@ class Pow2Plan {
         tp.timeout_ticks = rt->team_timeout_ticks();
         static const int ablate = getenv("FFT_HIP_TEAM_ABLATE") ? atoi(getenv("FFT_HIP_TEAM_ABLATE")) : 0;  // profiling only
         tp.ablate = ablate;
+        static const int dma_split = getenv("FFT_HIP_TEAM_DMA_SPLIT") ? atoi(getenv("FFT_HIP_TEAM_DMA_SPLIT")) : 4;
+        tp.dma_split = dma_split;
+        static const int seat_rot = getenv("FFT_HIP_TEAM_SEAT_ROT") ? atoi(getenv("FFT_HIP_TEAM_SEAT_ROT")) : 0;
+        tp.seat_rot = seat_rot;
+        static const int tile_rot = getenv("FFT_HIP_TEAM_TILE_ROT") ? atoi(getenv("FFT_HIP_TEAM_TILE_ROT")) : 4;
+        tp.tile_rot = tile_rot;
         tp.trace = team.trace;
         tp.trace_events = team.trace_events;
         tp.scale = scale;

@@ -149,7 +149,7 @@ FFT_DEVICE void stockham_stage_rw(cpx<T> (&x)[H][E][V], const unsigned char* sme
     if (!first) {
         FFT_UNROLL
         for (int h = 0; h < H; h++) {
-            const vec16<T>* data = reinterpret_cast<const vec16<T>*>(smem_rd + h * group_bytes);
+            const lvec<T, V>* data = reinterpret_cast<const lvec<T, V>*>(smem_rd + h * group_bytes);
             FFT_UNROLL
             for (int m = 0; m < G; m++) {
                 const int u = r + (m << log2TPC);
@@ -158,9 +158,19 @@ FFT_DEVICE void stockham_stage_rw(cpx<T> (&x)[H][E][V], const unsigned char* sme
                 const int base = (kp << log2Lprev) + q;
                 FFT_UNROLL
                 for (int a = 0; a < R; a++) {
-                    vec16<T> v = data[((base + (a << log2Li)) << log2J) + j];
+                    lvec<T, V> v = data[((base + (a << log2Li)) << log2J) + j];
                     FFT_UNROLL
-                    for (int vv = 0; vv < V; vv++) x[h][m + G * a][vv] = swap_in ? cswap(v.c[vv]) : v.c[vv];
+                    for (int vv = 0; vv < V; vv++) x[h][m + G * a][vv] = v.c[vv];
+                }
+            }
+        }
+        if (swap_in) {  // wave-uniform: one scalar branch, not a select per value
+            FFT_UNROLL
+            for (int h = 0; h < H; h++) {
+                FFT_UNROLL
+                for (int e = 0; e < E; e++) {
+                    FFT_UNROLL
+                    for (int vv = 0; vv < V; vv++) x[h][e][vv] = cswap(x[h][e][vv]);
                 }
             }
         }
@@ -204,7 +214,7 @@ FFT_DEVICE void stockham_stage_rw(cpx<T> (&x)[H][E][V], const unsigned char* sme
         }
         FFT_UNROLL
         for (int h = 0; h < H; h++) {
-            vec16<T>* data = reinterpret_cast<vec16<T>*>(smem + h * group_bytes);
+            lvec<T, V>* data = reinterpret_cast<lvec<T, V>*>(smem + h * group_bytes);
             FFT_UNROLL
             for (int m = 0; m < G; m++) {
                 const int u = r + (m << log2TPC);
@@ -212,7 +222,7 @@ FFT_DEVICE void stockham_stage_rw(cpx<T> (&x)[H][E][V], const unsigned char* sme
                 const int kp = u >> log2Li;
                 FFT_UNROLL
                 for (int k = 0; k < R; k++) {
-                    vec16<T> v;
+                    lvec<T, V> v;
                     FFT_UNROLL
                     for (int vv = 0; vv < V; vv++) v.c[vv] = x[h][m + G * k][vv];
                     const int idx = ((kp + (k << log2P)) << log2Li) + q;

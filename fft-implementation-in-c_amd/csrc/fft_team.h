@@ -66,6 +66,9 @@ struct TeamParams {
     int o_sb1, o_sa2, o_sb2, o_t0, o_t1;
     int sa1_bits, sa2_bits, t0_bits;
     long long timeout_ticks;  // bound of every spin, in FFT_CLOCK ticks
+    int tile_rot;             // column_block(): seats rotate by this many blocks per tile
+    int seat_rot;             // experiments: seat = (registration order + seat_rot) mod TS
+    int dma_split;            // column-tile DMA: chunks [0, dma_split) go out after stage 1, the rest after stage 2
     int ablate;               // experiments: 1 skip the inter-pass twiddle, 2 skip the stages
     long long* trace;         // profiling: not NULL = every workgroup logs FFT_CLOCK at its first trace_events events
     int trace_events;
@@ -92,36 +95,77 @@ FFT_DEVICE bool team_all_arrived(unsigned* flags, int TS, unsigned gen, int lane
 
 #define FFT_TEAM_GEO(l1, l2, ca, cb, ts) ((l1) | ((l2) << 5) | ((ca) << 10) | ((cb) << 15) | ((ts) << 20))
 
-// All Stockham stages (radix 4, plus one radix-2 stage when log2L is odd) of one tile whose samples sit in the
-// LDS-DMA landing image `land` ([element][column], the stage layout): the first stage reads `land` and writes the
-// work image `work`, the others run in `work`.  `land_is_free` runs as soon as every wave has read `land`.
-template <typename T, int E, int V, class Hook>
-FFT_DEVICE void team_all_stages(cpx<T> (&x)[1][E][V], const unsigned char* land, unsigned char* work, const StageTw<T>& tw,
-                                int r, int j, int log2J, int log2TPC, int log2L, Hook&& land_is_free, bool swap_in) {
+// All Stockham stages of one tile whose samples sit in the LDS-DMA landing image `land` ([element][column], the
+// stage layout): radix-E stages (E = the thread's element count: 16 fp32, 8 fp64) plus one stage of the remaining
+// power of two.  The first stage reads `land` and writes the work image `work`, the others run in `work`.
+// `hook(s, total)` runs in the middle of stage s < total - 1, right after the barrier that says every wave has
+// read that stage's inputs: at s == 0 the landing image is free again.  This is where the kernel issues its memory
+// traffic, so that it flies under the remaining stages.
+template <class Hook>
+struct StageHookAt {
+    Hook& hook;
+    int s, total;
+    FFT_DEVICE void operator()() const { hook(s, total); }
+};
+
+template <typename T, int E, class Hook>
+FFT_DEVICE void team_all_stages(cpx<T> (&x)[1][E][1], const unsigned char* land, unsigned char* work, const StageTw<T>& tw,
+                                int r, int j, int log2J, int log2TPC, int log2L, Hook&& hook, bool swap_in) {
+    constexpr int log2E = Log2<E>::value;
     int log2Lprev = log2L, log2P = 0;
-    const int n_full = log2L >> 1;
-    const int rem = log2L & 1;
+    const int n_full = log2L / log2E;
+    const int rem = log2L - n_full * log2E;
+    const int total = n_full + (rem ? 1 : 0);
     FFT_UNROLL
     for (int s = 0; s < n_full; s++) {
-        if (s == 0)
-            stockham_stage_rw<T, E, 4, V, 1>(x, land, work, 0, tw, r, j, log2J, log2TPC, log2Lprev, log2P, false,
-                                             n_full + rem == 1, land_is_free, swap_in);
-        else
-            stockham_stage_rw<T, E, 4, V, 1>(x, work, work, 0, tw, r, j, log2J, log2TPC, log2Lprev, log2P, false,
-                                             s == n_full + rem - 1, StageNoHook());
+        StageHookAt<Hook> h{hook, s, total};
+        stockham_stage_rw<T, E, E, 1, 1>(x, s == 0 ? land : work, work, 0, tw, r, j, log2J, log2TPC, log2Lprev, log2P, false,
+                                         s == total - 1, h, s == 0 && swap_in);
     }
-    if (rem) stockham_stage_rw<T, E, 2, V, 1>(x, work, work, 0, tw, r, j, log2J, log2TPC, log2Lprev, log2P, false, true, StageNoHook());
+    // the remaining stage is always the last one: no exchange, no hook
+    if (rem == 1) stockham_stage_rw<T, E, 2, 1, 1>(x, work, work, 0, tw, r, j, log2J, log2TPC, log2Lprev, log2P, false, true, StageNoHook());
+    if (rem == 2) stockham_stage_rw<T, E, 4, 1, 1>(x, work, work, 0, tw, r, j, log2J, log2TPC, log2Lprev, log2P, false, true, StageNoHook());
+    if (E > 8 && rem == 3)
+        stockham_stage_rw<T, E, (E > 8 ? 8 : 2), 1, 1>(x, work, work, 0, tw, r, j, log2J, log2TPC, log2Lprev, log2P, false, true, StageNoHook());
 }
 
+// Two lanes (l, l ^ mask) hold the same slots of two ADJACENT rows (even lane: row i, odd lane: row i + 1).  For the
+// slot pair (s0, s1) each lane ends up with BOTH rows of ONE slot -- the even lane of s0, the odd lane of s1 -- i.e.
+// 16 contiguous bytes of an image whose rows are adjacent in memory: half as many, twice as wide stores.
+template <typename T>
+FFT_DEVICE void pair_rows(const cpx<T>& own_s0, const cpx<T>& own_s1, bool odd, int mask, vec16<T>& out) {
+    static_assert(vec16<T>::V == 2, "fp32 only: a 16-byte access holds two values");
+    const cpx<T> send = odd ? own_s0 : own_s1;
+    cpx<T> recv;
+    recv.re = FFT_SHFL_XOR(send.re, mask);
+    recv.im = FFT_SHFL_XOR(send.im, mask);
+    out.c[0] = odd ? recv : own_s0;  // row i
+    out.c[1] = odd ? own_s1 : recv;  // row i + 1
+}
+
+// ---------------------------------------------------------------------------
+// The kernel.  Per transform a workgroup signals NT + 1 "arrivals" on its team's flag line (generation numbers
+// count up across transforms); a wait is a poll of the whole line by every wave that needs it:
+//   a0        my hand-over of phases 0 and 1 (written while the column tiles were transformed) is in L2
+//   a1        my row tile of phase 0 has landed in LDS
+//   a(ph+2)   end of row phase ph < NT-1: my row tile of phase ph+1 has landed, my hand-over of phase ph+2 is in L2
+// Window S[q & 1] of the team holds the hand-over of phase q.  Who waits for what:
+//   reading  phase q   (DMA L2 -> LDS)  needs everybody's hand-over of q     : a0 for q <= 1, a(q) for q >= 2
+//   writing  phase q+2 (into S[q & 1])  needs everybody to have read phase q : a(q+1)
+//   the next transform's hand-over of phases 0, 1 needs everybody's last reads: aNT of this transform
 // NT = tiles per workgroup per step = n / (TS * tile elements); GEO != 0 bakes the geometry into the instantiation.
+// ---------------------------------------------------------------------------
 template <typename T, int NT, int GEO>
 FFT_KERNEL void FFT_LAUNCH_BOUNDS2(512, 2) team_fft_kernel(TeamParams<T> p) {
-    constexpr int E = 8;
-    constexpr int V = vec16<T>::V;
-    constexpr int log2V = Log2<V>::value;
+    constexpr int V16 = vec16<T>::V;  // complex values per 16-byte lane access of HBM / L2: 2 (fp32) or 1 (fp64)
+    constexpr int log2V16 = Log2<V16>::value;
+    constexpr int E = 8 * V16;        // elements per thread, all of ONE column: radix-16 (fp32) / radix-8 (fp64) stages
+    constexpr int log2E = Log2<E>::value;
     constexpr int SZ = (int)sizeof(cpx<T>);
-    constexpr int EP = E / NT;  // register slots (rows r + TPC*e) that one phase hands over
+    constexpr int EP = E / NT;                     // register slots (rows r + TPC*e) that one phase hands over
+    constexpr int NK = NT > 2 ? NT - 2 : 0;        // phases whose hand-over waits in registers (phases 0, 1 go out at once)
     constexpr int log2NT = Log2<NT>::value;
+    constexpr int NARR = NT + 1;                   // arrivals per transform
     static_assert(NT == 1 || NT == 2 || NT == 4, "the team's register files hold at most 4 tiles per workgroup");
     FFT_DYN_SMEM(smem);
 
@@ -133,10 +177,10 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(512, 2) team_fft_kernel(TeamParams<T> p) {
     const int log2CB = GEO ? ((GEO >> 15) & 31) : p.log2CB;
     const int log2TS = GEO ? ((GEO >> 20) & 31) : p.log2TS;
     const int TS = 1 << log2TS;
-    // step A: thread (jA, rA) owns rows n1 = rA + TPCA*e of columns V*jA .. V*jA + V-1 of its tile
-    const int log2TPCA = log2L1 - 3, log2JA = log2CA - log2V;
-    // step B: thread (jB, rB) owns samples n2 = rB + TPCB*e of rows V*jB .. V*jB + V-1 of its tile
-    const int log2TPCB = log2L2 - 3, log2JB = log2CB - log2V;
+    // step A: thread (jA, rA) owns rows n1 = rA + TPCA*e of column jA of its tile;  step B: thread (jB, rB) owns
+    // samples n2 = rB + TPCB*e of row jB of its tile
+    const int log2TPCA = log2L1 - log2E;
+    const int log2TPCB = log2L2 - log2E;
     const long long n = 1ll << (log2L1 + log2L2);
     const unsigned tile_bytes = (unsigned)SZ << (log2L1 + log2CA);
     const unsigned phase_bytes = tile_bytes << log2TS;
@@ -145,6 +189,7 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(512, 2) team_fft_kernel(TeamParams<T> p) {
     unsigned char* const land = smem;
     unsigned char* const work = smem + tile_bytes;
     unsigned char* const tab_bytes = smem + 2 * tile_bytes;
+    const unsigned land_lds = FFT_LDS_ADDR(land);
     {
         const vec16<T>* src = reinterpret_cast<const vec16<T>*>(p.tables);
         vec16<T>* dst = reinterpret_cast<vec16<T>*>(tab_bytes);
@@ -152,14 +197,14 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(512, 2) team_fft_kernel(TeamParams<T> p) {
     }
     const cpx<T>* tab = reinterpret_cast<const cpx<T>*>(tab_bytes);
     volatile unsigned* sh = reinterpret_cast<volatile unsigned*>(tab_bytes + p.tables_bytes);
-    StageTw<T> twA, twB;
+    StageTw<T> twA, twB;  // single-level stage table up to 8 KiB, else two-level (same rule as the planner)
     twA.sa = tab;
     twA.sb = tab + p.o_sb1;
-    twA.sa_bits = p.sa1_bits;
+    twA.sa_bits = ((SZ << log2L1) > 8192) ? (log2L1 + 1) / 2 : log2L1;
     twA.log2L = log2L1;
     twB.sa = tab + p.o_sa2;
     twB.sb = tab + p.o_sb2;
-    twB.sa_bits = p.sa2_bits;
+    twB.sa_bits = ((SZ << log2L2) > 8192) ? (log2L2 + 1) / 2 : log2L2;
     twB.log2L = log2L2;
 
     // ---- team formation: who shares my L2?
@@ -186,195 +231,260 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(512, 2) team_fft_kernel(TeamParams<T> p) {
         sh[0] = slot;
         sh[1] = xcc;
         sh[2] = ok;
-        sh[3] = 0;  // abort word of the barrier
+        sh[3] = 0;  // set when a team wait timed out: later waits return at once, the status word tells the host
     }
     FFT_SYNC();
     if (!sh[2]) return;
-    const int c = (int)FFT_UNIFORM(sh[0]);  // my seat in the team
+    const int c = (int)((FFT_UNIFORM(sh[0]) + (unsigned)p.seat_rot) & (unsigned)(TS - 1));  // my seat in the team
     const int team = (int)FFT_UNIFORM(sh[1]);
 
     unsigned char* const sbase = p.scratch + (size_t)team * 2 * phase_bytes;
     unsigned* const flags = p.ctl + TEAM_CTL_FLAGS + 32 * team;
-    unsigned gen = 0;  // phases completed by this team
 
-    cpx<T> keep[NT][E][V];
     int n_ev = 0;
     auto ev = [&]() __attribute__((always_inline)) {  // profiling timeline (tools/team_trace.py); one scalar branch when off
-        if (p.trace && tid_invariant == 0 && n_ev < p.trace_events) {
+        if (p.trace && tid_invariant == 0 && n_ev < p.trace_events - 1) {  // the last slot holds (team << 8 | seat)
             p.trace[(long long)FFT_BID * p.trace_events + n_ev] = FFT_CLOCK();
             n_ev++;
         }
     };
     ev();  // 0: team formed
+    if (p.trace && tid_invariant == 0 && p.trace_events > 1) p.trace[(long long)FFT_BID * p.trace_events + p.trace_events - 1] = (team << 8) | c;
 
-    // LDS-DMA of column tile t of a transform into the landing image: element l = rA + TPCA*e of columns
-    // V*jA.. goes to image slot (l * JA + jA) = e * nthreads + tid: lane-linear, as the DMA requires
-    auto dma_column_tile = [&](const cpx<T>* inb, int t) __attribute__((always_inline)) {
+    // every member has stored generation >= g on the team's flag line (polled by each wave for itself)
+    auto wait_all = [&](unsigned g) __attribute__((always_inline)) {
+        if (sh[3]) return;
+        const long long t0 = FFT_CLOCK();
+        while (!team_all_arrived(flags, TS, g, tid_invariant & (FFT_TEAM_POLL_LANES - 1))) {
+            if (FFT_CLOCK() - t0 > p.timeout_ticks) {
+                FFT_ATOMIC_STORE_AGENT(&p.ctl[TEAM_CTL_STATUS], (unsigned)TEAM_STATUS_TIMEOUT);
+                sh[3] = 1;
+                break;
+            }
+            FFT_SLEEP();
+        }
+    };
+    // call with every wave's relevant memory operations complete and behind a workgroup barrier
+    auto arrive = [&](unsigned g) __attribute__((always_inline)) {
+        if (tid_invariant == 0) FFT_L2_FLAG_STORE(&flags[c], g);
+    };
+
+    cpx<T> keep[NT][NK * EP + 1];  // [tile][slot - 2*EP]: the hand-over of phases >= 2
+
+    // Column tile t of this workgroup is block column_block(t) of the transform's L2/CA column blocks.  The team covers
+    // one contiguous band of TS blocks per t; WHICH block of the band a seat takes rotates with t: on MI355X two of the
+    // sixteen 128-byte line positions of the band read measurably slower (+1.3 us per tile), and the rotation hands
+    // each seat at most one of them per transform instead of all four to the same four seats (skew at the team waits).
+    auto column_block = [&](int t) __attribute__((always_inline)) { return (t << log2TS) + ((c + p.tile_rot * t) & (TS - 1)); };
+
+    // LDS-DMA of column tile t of a transform into the landing image.  The image is [row][CA columns], filled
+    // lane-linearly in 16-byte chunks: chunk g = i * nthreads + tid is row g / (CA/V16), columns V16 * (g mod CA/V16)...
+    auto dma_column_tile = [&](const cpx<T>* inb, int t, int i0, int i1) __attribute__((always_inline)) {
         int tid = tid_invariant;
         FFT_OPAQUE(tid);
-        const int jA = tid & ((1 << log2JA) - 1), rA = tid >> log2JA;
-        const int c0 = ((t << log2TS) + c) << log2CA;  // the team's workgroups read one contiguous TS*CA-column band
-        const cpx<T>* src = inb + ((long long)rA << log2L2) + c0 + V * jA;
-        unsigned char* dst = land + (size_t)tid * 16;
+        const int log2CPR = log2CA - log2V16;  // 16-byte chunks per image row
+        const int c0 = column_block(t) << log2CA;  // the team's workgroups read one contiguous TS*CA-column band
+        const cpx<T>* src = inb + ((long long)(tid >> log2CPR) << log2L2) + c0 + V16 * (tid & ((1 << log2CPR) - 1));
+        const long long step = (long long)(nthreads >> log2CPR) << log2L2;  // rows per wave-front of chunks
         FFT_UNROLL
-        for (int e = 0; e < E; e++)
-            FFT_GLDS16(src + ((long long)e << (log2TPCA + log2L2)), dst + (size_t)e * nthreads * 16, 0);
+        for (int i = 0; i < 8; i++)
+            if (i >= i0 && i < i1) FFT_DMA16(src + i * step, land, land_lds, (unsigned)(i * nthreads + tid) * 16u);
+    };
+    // LDS-DMA of my row tile of the window `sb` (tile_bytes contiguous bytes), served by the XCD's L2
+    auto dma_row_tile = [&](const unsigned char* sb) __attribute__((always_inline)) {
+        int tid = tid_invariant;
+        FFT_OPAQUE(tid);
+        const unsigned char* src = sb + (size_t)c * tile_bytes + (size_t)tid * 16;
+        FFT_UNROLL
+        for (int i = 0; i < 8; i++)
+            FFT_DMA16_L2(src + (size_t)i * nthreads * 16, land, land_lds, (unsigned)(i * nthreads + tid) * 16u);
+    };
+    // Hand over the EP values y[] (rows rA + TPCA*ee of the phase, column c0 + jA) into window `sb`.  Row cp*CB + i of
+    // the phase goes to workgroup cp, whose window image is its row tile in the stage layout [n2][CB rows].  fp32: the
+    // lanes of rows i, i+1 (rA even / odd, CA lanes apart) pair up so that every store is 16 bytes.
+    auto hand_over = [&](unsigned char* sb, const cpx<T> (&y)[EP], int tt, int rA, int jA) __attribute__((always_inline)) {
+        const int n2 = (column_block(tt) << log2CA) + jA;
+        if constexpr (V16 == 2) {
+            const bool odd = (rA & 1) != 0;
+            FFT_UNROLL
+            for (int q = 0; q < EP / 2; q++) {
+                const int row = (rA & ~1) + (((2 * q) + (odd ? 1 : 0)) << log2TPCA);  // even row of the pair
+                const int cp = row >> log2CB, i = row & ((1 << log2CB) - 1);
+                vec16<T> v;
+                pair_rows<T>(y[2 * q], y[2 * q + 1], odd, 1 << log2CA, v);
+                *reinterpret_cast<vec16<T>*>(sb + (size_t)cp * tile_bytes + (((size_t)n2 << log2CB) + i) * SZ) = v;
+            }
+        } else {
+            FFT_UNROLL
+            for (int ee = 0; ee < EP; ee++) {
+                const int row = rA + (ee << log2TPCA);
+                const int cp = row >> log2CB, i = row & ((1 << log2CB) - 1);
+                *reinterpret_cast<cpx<T>*>(sb + (size_t)cp * tile_bytes + (((size_t)n2 << log2CB) + i) * SZ) = y[ee];
+            }
+        }
     };
 
     bool have_first = false;
-    for (int b = team; b < p.nb; b += p.n_teams) {
+    unsigned g0 = 1;  // generation of this transform's a0
+    for (int b = team; b < p.nb; b += p.n_teams, g0 += NARR) {
         const cpx<T>* inb = p.in + (long long)b * n;
         cpx<T>* outb = p.out + (long long)b * n;
-        if (!have_first) dma_column_tile(inb, 0);
+        if (!have_first) dma_column_tile(inb, 0, 0, 8);
 
-        // ================= step A: L2-strided column FFTs of length L1, results stay in registers
+        // ================= step A: L2-strided column FFTs of length L1; phases 0, 1 are handed over at once
         FFT_NOUNROLL
         for (int t = 0; t < NT; t++) {
             int tid = tid_invariant;
             FFT_OPAQUE(tid);
-            const int jA = tid & ((1 << log2JA) - 1), rA = tid >> log2JA;
-            cpx<T> x[1][E][V];
+            const int jA = tid & ((1 << log2CA) - 1), rA = tid >> log2CA;
+            cpx<T> x[1][E][1];
             FFT_WAIT_VM0();   // my part of the tile has landed ...
             FFT_SYNC_LDS();   // ... everybody's has; the work image is free (previous tile's last stage has read it)
             ev();  // A: tile landed
             const bool more = (t + 1 < NT);
             if (!(p.ablate & 2)) {
-                team_all_stages<T, E, V>(x, land, work, twA, rA, jA, log2JA, log2TPCA, log2L1, [&]() {
-                    if (more) dma_column_tile(inb, t + 1);  // flies during the remaining stages
+                team_all_stages<T, E>(x, land, work, twA, rA, jA, log2CA, log2TPCA, log2L1, [&](int s, int total) {
+                    // the next tile flies during the remaining stages; issued in two halves (a CU's memory queue is short)
+                    if (more) {
+                        if (total >= 3) {
+                            if (s == 0) dma_column_tile(inb, t + 1, 0, p.dma_split);
+                            if (s == 1) dma_column_tile(inb, t + 1, p.dma_split, 8);
+                        } else if (s == 0) {
+                            dma_column_tile(inb, t + 1, 0, 8);
+                        }
+                    }
                 }, p.inverse != 0);  // inverse = forward transform between two re<->im swaps: first one here
             } else if (more) {
                 FFT_SYNC_LDS();
-                dma_column_tile(inb, t + 1);
+                dma_column_tile(inb, t + 1, 0, 8);
             }
             if (!(p.ablate & 1)) {  // W_n^(k1 n2), two-level LDS table
                 const cpx<T>* t0 = tab + p.o_t0;
                 const cpx<T>* t1 = tab + p.o_t1;
                 const unsigned m0 = (1u << p.t0_bits) - 1u;
-                const unsigned c0 = (unsigned)(((t << log2TS) + c) << log2CA);
+                const unsigned c0 = (unsigned)(column_block(t) << log2CA);
                 FFT_UNROLL
                 for (int e = 0; e < E; e++) {
-                    const unsigned K = (unsigned)(rA + (e << log2TPCA));
-                    FFT_UNROLL
-                    for (int vv = 0; vv < V; vv++) {
-                        const unsigned m = K * (c0 + V * jA + vv);
-                        x[0][e][vv] = cmul(x[0][e][vv], cmul(t0[m & m0], t1[m >> p.t0_bits]));
-                    }
+                    const unsigned m = (unsigned)(rA + (e << log2TPCA)) * (c0 + jA);
+                    x[0][e][0] = cmul(x[0][e][0], cmul(t0[m & m0], t1[m >> p.t0_bits]));
                 }
             }
+            // windows S0, S1 were last read by the previous transform's final phases: everybody is past them?
+            if (t == 0 && g0 > 1) wait_all(g0 - 1);
             FFT_UNROLL
-            for (int tt = 0; tt < NT; tt++) {
-                if (t == tt) {
-                    FFT_UNROLL
-                    for (int e = 0; e < E; e++) {
+            for (int ph = 0; ph < (NT < 2 ? NT : 2); ph++) {
+                cpx<T> y[EP];
+                FFT_UNROLL
+                for (int ee = 0; ee < EP; ee++) y[ee] = x[0][ph * EP + ee][0];
+                hand_over(sbase + (size_t)ph * phase_bytes, y, t, rA, jA);
+            }
+            if constexpr (NK > 0) {
+                FFT_UNROLL
+                for (int tt = 0; tt < NT; tt++) {
+                    if (t == tt) {
                         FFT_UNROLL
-                        for (int vv = 0; vv < V; vv++) keep[tt][e][vv] = x[0][e][vv];
+                        for (int k = 0; k < NK * EP; k++) keep[tt][k] = x[0][2 * EP + k][0];
                     }
                 }
             }
-            ev();  // A: tile transformed
+            ev();  // A: tile transformed, phases 0/1 hand-over issued
         }
+        FFT_WAIT_VM0();
+        FFT_SYNC_LDS();
+        arrive(g0);  // a0
+        ev();        // A: hand-over of phases 0, 1 in L2
 
-        // ================= step B: NT phases of (hand over through L2, row FFTs of length L2, transposed store)
+        // ================= step B: NT phases of (row FFTs of length L2, transposed store)
+        wait_all(g0);
+        ev();  // B: everybody's hand-over of phases 0, 1 in L2
+        dma_row_tile(sbase);
+        FFT_WAIT_VM0();
+        FFT_SYNC_LDS();
+        arrive(g0 + 1);  // a1
+        ev();  // B: row tile 0 landed
         FFT_NOUNROLL
         for (int ph = 0; ph < NT; ph++) {
             int tid = tid_invariant;
             FFT_OPAQUE(tid);
-            const int jA = tid & ((1 << log2JA) - 1), rA = tid >> log2JA;
-            const int jB = tid & ((1 << log2JB) - 1), rB = tid >> log2JB;
-            unsigned char* const sb = sbase + (size_t)(gen & 1u) * phase_bytes;
-            {
-                // This phase hands over rows k1 = ph*L1/NT + rA + TPCA*ee, ee < EP.  Row cp*CB + i of the phase goes
-                // to workgroup cp, whose window image is its row tile in the stage layout [n2][CB rows]: the 8
-                // (or 16) bytes of one value per store, CB lanes filling one CB*SZ-byte segment.
-                cpx<T> y[EP][NT][V];
-                FFT_UNROLL
-                for (int pp = 0; pp < NT; pp++) {
-                    if (ph == pp) {
-                        FFT_UNROLL
-                        for (int ee = 0; ee < EP; ee++) {
+            const int jA = tid & ((1 << log2CA) - 1), rA = tid >> log2CA;
+            const int jB = tid & ((1 << log2CB) - 1), rB = tid >> log2CB;
+            cpx<T> x[1][E][1];
+            const bool next_transform = (ph == NT - 1) && (b + p.n_teams < p.nb);
+            auto traffic = [&](int s, int total) __attribute__((always_inline)) {
+                if (s == 0) {  // the landing image is free
+                    if (ph + 1 < NT) {
+                        if (ph >= 1) wait_all(g0 + ph + 1);  // everybody's hand-over of phase ph+1 (a0 covers phase 1)
+                        dma_row_tile(sbase + (size_t)((ph + 1) & 1) * phase_bytes);
+                    } else if (next_transform) {
+                        dma_column_tile(inb + (long long)p.n_teams * n, 0, 0, 8);
+                    }
+                }
+                // hand-over of phase ph+2: as early as its wait allows, so that the stores are long in L2 when the phase
+                // closes -- phase 0 gives the others one more stage to report their read of phase 0 (a1)
+                if (s == ((total >= 3 && ph == 0) ? 1 : 0)) {
+                    if constexpr (NK > 0) {
+                        if (ph + 2 < NT) {  // hand over phase ph+2 into the window phase ph was read from
+                            if (ph == 0) wait_all(g0 + 1);  // everybody has read phase 0 (phase 1: known since the wait above)
                             FFT_UNROLL
-                            for (int tt = 0; tt < NT; tt++) {
-                                FFT_UNROLL
-                                for (int vv = 0; vv < V; vv++) y[ee][tt][vv] = keep[tt][pp * EP + ee][vv];
+                            for (int pp = 0; pp < NK; pp++) {
+                                if (ph == pp) {
+                                    FFT_UNROLL
+                                    for (int tt = 0; tt < NT; tt++) {
+                                        cpx<T> y[EP];
+                                        FFT_UNROLL
+                                        for (int ee = 0; ee < EP; ee++) y[ee] = keep[tt][pp * EP + ee];
+                                        hand_over(sbase + (size_t)(ph & 1) * phase_bytes, y, tt, rA, jA);
+                                    }
+                                }
                             }
                         }
                     }
                 }
-                FFT_UNROLL
-                for (int ee = 0; ee < EP; ee++) {
-                    const int row = rA + (ee << log2TPCA);  // cp * CB + i
-                    const int cp = row >> log2CB, i = row & ((1 << log2CB) - 1);
-                    unsigned char* dst = sb + (size_t)cp * tile_bytes + (size_t)i * SZ;
-                    FFT_UNROLL
-                    for (int tt = 0; tt < NT; tt++) {
-                        const int n2 = (((tt << log2TS) + c) << log2CA) + V * jA;
-                        FFT_UNROLL
-                        for (int vv = 0; vv < V; vv++)
-                            *reinterpret_cast<cpx<T>*>(dst + ((size_t)(n2 + vv) << log2CB) * SZ) = y[ee][tt][vv];
-                    }
-                }
-            }
-            // ---- team barrier: my stores are in L2, then everybody's are
-            ev();  // B: hand-over stores issued
-            FFT_WAIT_VM0();
-            FFT_SYNC();
-            ev();  // B: hand-over stores in L2
-            gen++;
-            if (tid < FFT_TEAM_POLL_LANES) {
-                if (tid == 0) FFT_L2_FLAG_STORE(&flags[c], gen);
-                const long long t0 = FFT_CLOCK();
-                while (!team_all_arrived(flags, TS, gen, tid)) {
-                    if (FFT_CLOCK() - t0 > p.timeout_ticks) {
-                        if (tid == 0) {
-                            FFT_ATOMIC_STORE_AGENT(&p.ctl[TEAM_CTL_STATUS], (unsigned)TEAM_STATUS_TIMEOUT);
-                            sh[3] = 1;
-                        }
-                        break;
-                    }
-                    FFT_SLEEP();
-                }
-            }
-            FFT_SYNC();
-            if (sh[3]) return;
-            ev();  // B: team barrier passed
-
-            // ---- my row tile: tile_bytes contiguous bytes of the window, L2 -> LDS (sc1: never through my L1)
-            {
-                const unsigned char* src = sb + (size_t)c * tile_bytes + (size_t)tid * 16;
-                unsigned char* dst = land + (size_t)tid * 16;
-                FFT_UNROLL
-                for (int e = 0; e < E; e++) FFT_GLDS16(src + (size_t)e * nthreads * 16, dst + (size_t)e * nthreads * 16, 16);
-            }
-            FFT_WAIT_VM0();
-            FFT_SYNC_LDS();
-            ev();  // B: row tile landed
-            cpx<T> x[1][E][V];
-            const bool next_transform = (ph == NT - 1) && (b + p.n_teams < p.nb);
+            };
             if (!(p.ablate & 2)) {
-                team_all_stages<T, E, V>(x, land, work, twB, rB, jB, log2JB, log2TPCB, log2L2, [&]() {
-                    // the next transform's first column tile flies during the last row FFTs and stores
-                    if (next_transform) dma_column_tile(inb + (long long)p.n_teams * n, 0);
-                }, false);
-            } else if (next_transform) {
+                team_all_stages<T, E>(x, land, work, twB, rB, jB, log2CB, log2TPCB, log2L2, traffic, false);
+            } else {
                 FFT_SYNC_LDS();
-                dma_column_tile(inb + (long long)p.n_teams * n, 0);
+                traffic(0, 1);
             }
             if (next_transform) have_first = true;
             ev();  // B: rows transformed
-            // X[k1 + L1*k2]: slot e holds k2 = rB + TPCB*e of rows k1 = ph*L1/NT + c*CB + V*jB + (0..V-1)
-            const long long k1 = ((long long)ph << (log2L1 - log2NT)) + ((long long)c << log2CB) + V * jB;
-            FFT_UNROLL
-            for (int e = 0; e < E; e++) {
-                const long long K = rB + (e << log2TPCB);
-                vec16<T> v;
+            // X[k1 + L1*k2]: slot e holds k2 = rB + TPCB*e of row k1 = ph*L1/NT + c*CB + jB.  fp32: the lanes of rows
+            // jB, jB+1 pair up (16-byte stores, as in the hand-over)
+            const long long k1 = ((long long)ph << (log2L1 - log2NT)) + ((long long)c << log2CB);
+            if (p.inverse) {
                 FFT_UNROLL
-                for (int vv = 0; vv < V; vv++) {
-                    cpx<T> z = p.inverse ? cswap(x[0][e][vv]) : x[0][e][vv];
-                    v.c[vv] = (p.scale != (T)1) ? cscale(z, p.scale) : z;
+                for (int e = 0; e < E; e++) x[0][e][0] = cswap(x[0][e][0]);
+            }
+            if (p.scale != (T)1) {
+                FFT_UNROLL
+                for (int e = 0; e < E; e++) x[0][e][0] = cscale(x[0][e][0], p.scale);
+            }
+            if constexpr (V16 == 2) {
+                const bool odd = (jB & 1) != 0;
+                FFT_UNROLL
+                for (int q = 0; q < E / 2; q++) {
+                    const long long K = rB + (((2 * q) + (odd ? 1 : 0)) << log2TPCB);
+                    vec16<T> v;
+                    pair_rows<T>(x[0][2 * q][0], x[0][2 * q + 1][0], odd, 1, v);
+                    *reinterpret_cast<vec16<T>*>(outb + (K << log2L1) + k1 + (jB & ~1)) = v;
                 }
-                *reinterpret_cast<vec16<T>*>(outb + (K << log2L1) + k1) = v;
+            } else {
+                FFT_UNROLL
+                for (int e = 0; e < E; e++) {
+                    const long long K = rB + (e << log2TPCB);
+                    *reinterpret_cast<cpx<T>*>(outb + (K << log2L1) + k1 + jB) = x[0][e][0];
+                }
             }
             ev();  // B: result stores issued
+            if (ph + 1 < NT) {
+                // everything but my 8 result stores is complete: the next row tile has landed, my hand-over of phase
+                // ph+2 is in L2
+                FFT_WAIT_VM_LE8();
+                FFT_SYNC_LDS();
+                arrive(g0 + ph + 2);  // a(ph+2)
+                ev();  // B: phase closed
+            }
         }
     }
 }

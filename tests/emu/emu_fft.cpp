@@ -20,8 +20,10 @@ long long clock_ticks() {  // 100 MHz, like the device's wall clock
     return (long long)ts.tv_sec * 100000000ll + ts.tv_nsec / 10;
 }
 
+static thread_local unsigned* g_xchg = nullptr;  // 1024 words per workgroup
+
 unsigned shfl_xor_u32(unsigned v, int mask) {
-    static unsigned xchg[1024];
+    unsigned* xchg = g_xchg;
     xchg[threadIdx_.x] = v;
     sync_threads();
     unsigned r = xchg[(threadIdx_.x & ~63u) | ((threadIdx_.x ^ (unsigned)mask) & 63u)];
@@ -36,6 +38,7 @@ void Runtime::run_grid(long long grid, int block, size_t smem, const std::functi
     unsigned char* lds_base = lds.data() + ((16 - ((uintptr_t)lds.data() & 15)) & 15);
     pthread_barrier_t barrier;
     pthread_barrier_init(&barrier, nullptr, (unsigned)block);
+    std::vector<unsigned> xchg(1024);
     std::vector<std::thread> th;
     th.reserve(block);
     for (int t = 0; t < block; t++) {
@@ -43,6 +46,7 @@ void Runtime::run_grid(long long grid, int block, size_t smem, const std::functi
             threadIdx_ = {(unsigned)t, 0, 0};
             smem_ = lds_base;
             g_barrier = &barrier;
+            g_xchg = xchg.data();
             for (long long b = 0; b < grid; b++) {
                 blockIdx_ = {(unsigned)b, 0, 0};
                 body();
@@ -61,6 +65,7 @@ void Runtime::run_grid_coresident(long long grid, int block, size_t smem, const 
     gridDim_ = {(unsigned)grid, 1, 1};
     std::vector<std::vector<unsigned char>> lds((size_t)grid, std::vector<unsigned char>(smem + 64, 0xFF));
     std::vector<pthread_barrier_t> barriers((size_t)grid);
+    std::vector<std::vector<unsigned>> xchg((size_t)grid, std::vector<unsigned>(1024));
     for (auto& b : barriers) pthread_barrier_init(&b, nullptr, (unsigned)block);
     std::vector<std::thread> th;
     th.reserve((size_t)grid * block);
@@ -72,6 +77,7 @@ void Runtime::run_grid_coresident(long long grid, int block, size_t smem, const 
                 unsigned char* base = lds[(size_t)b].data();
                 smem_ = base + ((16 - ((uintptr_t)base & 15)) & 15);
                 g_barrier = &barriers[(size_t)b];
+                g_xchg = xchg[(size_t)b].data();
                 body();
             });
         }

@@ -12,8 +12,18 @@ import fftlib  # noqa: E402
 import oracle_lib as O  # noqa: E402
 
 NT = 4
-A_EV = ["A landed", "A done"]
-B_EV = ["B st issued", "B st in L2", "B barrier", "B landed", "B rows done", "B out issued"]
+
+
+def event_names():
+    names = []
+    for k in range(NT):
+        names += ["A landed %d" % k, "A done+handover %d" % k]
+    names += ["A handover in L2 (a0)", "B all a0", "B tile 0 landed (a1)"]
+    for k in range(NT):
+        names += ["B rows done %d" % k, "B out issued %d" % k]
+        if k + 1 < NT:
+            names += ["B phase closed %d" % k]
+    return names
 
 
 def main():
@@ -26,8 +36,9 @@ def main():
     out = fftlib.DeviceBuffer(x.nbytes)
     buf.upload(x)
     plan = fftlib.Plan(n, batch, -1, np.complex64)
-    per = NT * len(A_EV) + NT * len(B_EV)
-    events = 1 + per * 6
+    names = event_names()
+    per = len(names)
+    events = 2 + per * 6
     tr = fftlib.DeviceBuffer(256 * events * 8)
     tr.upload(np.zeros(256 * events, dtype=np.int64))
     plan.timed(buf.ptr, out.ptr, 3)
@@ -39,11 +50,20 @@ def main():
     t = tr.download((256, events), np.int64).astype(np.float64) / 100.0  # us
     t0 = t[:, 0].min()
     print("team formation: first %.2f us, last %.2f us after the earliest workgroup" % (t[:, 0].min() - t0, t[:, 0].max() - t0))
-    names = []
-    for k in range(NT):
-        names += ["%s %d" % (a, k) for a in A_EV]
-    for k in range(NT):
-        names += ["%s %d" % (b, k) for b in B_EV]
+    seat = tr.download((256, events), np.int64)[:, events - 1]
+    a_dur = np.zeros(256)
+    for tr_i in range(1, 5):
+        base = 1 + per * tr_i
+        a_dur += (t[:, base + 2 * NT - 1] - t[:, base - 1]) / 4
+    by_seat = np.zeros(32)
+    for w in range(256):
+        by_seat[int(seat[w]) & 255] += a_dur[w] / 8
+    print("A-step duration by seat (mean over teams and transforms 1-4), us:")
+    print("  " + " ".join("%.1f" % v for v in by_seat))
+    by_team = np.zeros(8)
+    for w in range(256):
+        by_team[int(seat[w]) >> 8] += a_dur[w] / 32
+    print("A-step duration by team: " + " ".join("%.1f" % v for v in by_team))
     for tr_i in (1, 3):  # second and fourth transform of each team
         base = 1 + per * tr_i
         prev = t[:, base - 1]
