@@ -64,11 +64,11 @@ struct SplitRadix {
         cpx<T> t1 = mul_w16<T, K * (16 / N)>(o1[K]);
         cpx<T> t3 = mul_w16<T, 3 * K * (16 / N)>(o3[K]);
         cpx<T> s = cadd(t1, t3);
-        cpx<T> d = mul_neg_i(csub(t1, t3));
+        cpx<T> d = csub(t1, t3);  // the odd outputs take -i d: folded into the add / subtract (cadd_mni / csub_mni)
         y[K] = cadd(ev[K], s);
         y[K + 2 * Q] = csub(ev[K], s);
-        y[K + Q] = cadd(ev[K + Q], d);
-        y[K + 3 * Q] = csub(ev[K + Q], d);
+        y[K + Q] = cadd_mni(ev[K + Q], d);
+        y[K + 3 * Q] = csub_mni(ev[K + Q], d);
         if constexpr (K + 1 < Q) combine<K + 1>(ev, o1, o3, y);
     }
     static FFT_DEVICE void run(const cpx<T>* x, cpx<T>* y) {

@@ -195,6 +195,59 @@ FFT_DEVICE cpx<T> mul_pos_i(cpx<T> a) { return mk<T>(-a.im, a.re); }  // a * (+i
 template <typename T>
 FFT_DEVICE cpx<T> cswap(cpx<T> a) { return mk<T>(a.im, a.re); }
 
+// a + (-i) b  and  a - (-i) b: the L-shaped butterfly's odd outputs (fft_codelets.h) without a separate rotation
+template <typename T>
+FFT_DEVICE cpx<T> cadd_mni(cpx<T> a, cpx<T> b) { return mk<T>(a.re + b.im, a.im - b.re); }
+template <typename T>
+FFT_DEVICE cpx<T> csub_mni(cpx<T> a, cpx<T> b) { return mk<T>(a.re - b.im, a.im + b.re); }
+
+#if !defined(FFT_EMU)
+// fp32 on gfx950: a complex value is one 64-bit VGPR pair and the arithmetic below is PACKED math on that pair
+// (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 with op_sel / neg modifiers doing the re<->im swizzles), written out
+// because hipcc otherwise re-packs pairs of real parts and pairs of imaginary parts of DIFFERENT values and pays
+// for it in v_mov shuffles (a quarter of the vector instructions of a radix-16 stage, measured).  The kernels are
+// vector-ALU bound (2 waves per SIMD), so instruction count is time.  Non-template overloads: chosen over the
+// templates above for cpx<float>.
+typedef float fft_v2f __attribute__((ext_vector_type(2)));
+// (built from / split into the two members: a bit cast goes through memory and keeps the kernels' register arrays
+// from being promoted)
+FFT_DEVICE fft_v2f as_v2(cpx<float> a) {
+    fft_v2f v = {a.re, a.im};
+    return v;
+}
+FFT_DEVICE cpx<float> as_cpx(fft_v2f v) {
+    cpx<float> r;
+    r.re = v.x;
+    r.im = v.y;
+    return r;
+}
+FFT_DEVICE cpx<float> cadd(cpx<float> a, cpx<float> b) { return as_cpx(as_v2(a) + as_v2(b)); }
+FFT_DEVICE cpx<float> csub(cpx<float> a, cpx<float> b) { return as_cpx(as_v2(a) - as_v2(b)); }
+FFT_DEVICE cpx<float> cscale(cpx<float> a, float s) { return as_cpx(as_v2(a) * s); }
+FFT_DEVICE cpx<float> cmul(cpx<float> a, cpx<float> b) {
+    fft_v2f t, r;  // t = (a.re b.re, a.re b.im);  r = (-a.im b.im + t.lo, a.im b.re + t.hi)
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(as_v2(a)), "v"(as_v2(b)));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(as_v2(a)), "v"(as_v2(b)), "v"(t));
+    return as_cpx(r);
+}
+FFT_DEVICE cpx<float> cmul_conj(cpx<float> a, cpx<float> b) {  // a * conj(b)
+    fft_v2f t, r;  // t = (a.re b.re, -a.re b.im);  r = (a.im b.im + t.lo, a.im b.re + t.hi)
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(t) : "v"(as_v2(a)), "v"(as_v2(b)));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(as_v2(a)), "v"(as_v2(b)), "v"(t));
+    return as_cpx(r);
+}
+FFT_DEVICE cpx<float> cadd_mni(cpx<float> a, cpx<float> b) {  // (a.re + b.im, a.im - b.re)
+    fft_v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(as_v2(a)), "v"(as_v2(b)));
+    return as_cpx(r);
+}
+FFT_DEVICE cpx<float> csub_mni(cpx<float> a, cpx<float> b) {  // (a.re - b.im, a.im + b.re)
+    fft_v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(as_v2(a)), "v"(as_v2(b)));
+    return as_cpx(r);
+}
+#endif
+
 // One 16-byte lane access: 2 adjacent complex32 or 1 complex128.  Every HBM
 // and LDS data access of the tile kernels moves one of these per lane
 // (global_load_dwordx4 / ds_read_b128).

@@ -133,14 +133,18 @@ FFT_DEVICE void team_all_stages(cpx<T> (&x)[1][E][1], const unsigned char* land,
 // slot pair (s0, s1) each lane ends up with BOTH rows of ONE slot -- the even lane of s0, the odd lane of s1 -- i.e.
 // 16 contiguous bytes of an image whose rows are adjacent in memory: half as many, twice as wide stores.
 template <typename T>
-FFT_DEVICE void pair_rows(const cpx<T>& own_s0, const cpx<T>& own_s1, bool odd, int mask, vec16<T>& out) {
+FFT_DEVICE void pair_rows(cpx<T> own_s0, cpx<T> own_s1, bool odd, int mask, vec16<T>& out) {
     static_assert(vec16<T>::V == 2, "fp32 only: a 16-byte access holds two values");
-    const cpx<T> send = odd ? own_s0 : own_s1;
-    cpx<T> recv;
-    recv.re = FFT_SHFL_XOR(send.re, mask);
-    recv.im = FFT_SHFL_XOR(send.im, mask);
-    out.c[0] = odd ? recv : own_s0;  // row i
-    out.c[1] = odd ? own_s1 : recv;  // row i + 1
+    // selects on VALUES, component by component: a select between the two register-array elements themselves keeps
+    // the optimizer from promoting the array to registers
+    const T send_re = odd ? own_s0.re : own_s1.re;
+    const T send_im = odd ? own_s0.im : own_s1.im;
+    const T recv_re = FFT_SHFL_XOR(send_re, mask);
+    const T recv_im = FFT_SHFL_XOR(send_im, mask);
+    out.c[0].re = odd ? recv_re : own_s0.re;  // row i
+    out.c[0].im = odd ? recv_im : own_s0.im;
+    out.c[1].re = odd ? own_s1.re : recv_re;  // row i + 1
+    out.c[1].im = odd ? own_s1.im : recv_im;
 }
 
 // ---------------------------------------------------------------------------
