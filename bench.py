@@ -318,11 +318,18 @@ def main():
     # ---- device-side duration of the same K steps, HIP events on the stream the kernels run on
     ev_ms = plan.timed(x.data_ptr(), y.data_ptr(), args.steps)
     torch.cuda.synchronize()
-    # ---- per-pass kernel durations, one more execute with a HIP event after every pass launch
+    # which schedule ran?  0: the one-round-trip team kernel (fft_team.h) did the work; 1: its XCD teams could not be
+    # formed and the multi-pass fallback queued behind it did; -1: the plan has no team kernel (multi-pass schedule)
+    team_status = plan.team_status()
+    team = info.team_tiles > 0 and team_status == 0
+    # ---- per-launch kernel durations, one more execute with a HIP event after every launch
     per_pass = []
     if not info.bluestein_m:
-        prof = [plan.profile_passes(x.data_ptr(), y.data_ptr()) for _ in range(3)][-1]
-        per_pass = [{"pass": i, "launches_per_step": c, "avg_launch_ms": m / c, "ms_per_step": m} for i, (m, c) in enumerate(prof)]
+        prof = [plan.profile_passes(x.data_ptr(), y.data_ptr(), 6) for _ in range(3)][-1]
+        names = (["team_fft_kernel"] + ["fallback pass %d (returns at once)" % i for i in range(8)]) if team else \
+                ["tile_fft_kernel pass %d" % i for i in range(8)]
+        per_pass = [{"pass": i, "kernel": names[i], "launches_per_step": c, "avg_launch_ms": m / c, "ms_per_step": m}
+                    for i, (m, c) in enumerate(prof)]
     torch.cuda.synchronize()
 
     points_per_step = float(n) * batch * world
@@ -334,6 +341,19 @@ def main():
     n_groups = -(-batch // max(1, info.chunk_batch)) if info.n_passes > 1 else 1
     launches = (3 + 2 * max(1, info.n_passes) * n_groups) if info.bluestein_m else info.n_passes * n_groups
     units_per_launch = min(batch, info.chunk_batch) if info.n_passes > 1 else batch
+    if team:
+        # ONE team_fft_kernel launch carries the whole batch: every transform is read from HBM once and written once
+        # (the four-step transposition stays inside the XCDs), so the launch's own duration is the roofline denominator
+        n_groups, units_per_launch = 1, batch
+        team_ms = per_pass[0]["avg_launch_ms"] if per_pass else ev_ms_per_step
+        achieved = bytes_alg_per_step_gpu / (team_ms * 1e-3) / 1e9
+        kernel_desc = ("team_fft_kernel: ONE launch per step transforms all %d transforms, a whole transform per XCD "
+                       "(256 workgroups = 8 teams of 32, %d tiles per workgroup and step); the %d multi-pass launches "
+                       "queued behind it as its fallback return at once" % (batch, info.team_tiles, launches))
+    else:
+        kernel_desc = ("tile_fft_kernel: one launch per pass per group of %d transforms (%d launches per step); the "
+                       "dominant unit of work is the launch SET that carries a group through all %d passes"
+                       % (units_per_launch, launches, max(1, info.n_passes)))
 
     # HBM traffic from the PMC counters comes from separate rocprofv3 --pmc runs (never combined with tracing);
     # the committed summary is attached when it was taken on this same workload / plan shape.
@@ -342,6 +362,7 @@ def main():
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             pt = json.load(f)
         ent = pt.get(args.workload)
+        ent = pt.get(args.workload + ("_team" if team else ""))
         if ent and ent.get("factors") == [v for v in info.factors if v] and ent.get("units_per_launch") == units_per_launch:
             traffic = ent["hbm_bytes_per_launch_set"]
             traffic_note = ent["note"]
@@ -360,22 +381,24 @@ def main():
             "parallelism": "batch index sharded over %d GPU(s), one process per GPU, no collectives" % world,
             "algo": args.algo, "passes": info.n_passes, "factors": [v for v in info.factors if v],
             "chunk_batch": info.chunk_batch, "bluestein_m": info.bluestein_m,
+            "schedule": "team kernel: one HBM round trip, whole transform per XCD" if team else
+                        ("multi-pass (team kernel fell back)" if team_status == 1 else "multi-pass"),
+            "team_tiles": info.team_tiles, "team_status": team_status,
             "device": lib.fft_gpu_get_device_name().decode(),
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-            "kernel": "tile_fft_kernel: one launch per pass per group of %d transforms (%d launches per step); the "
-                      "dominant unit of work is the launch SET that carries a group through all %d passes"
-                      % (units_per_launch, launches, max(1, info.n_passes)),
+            "kernel": kernel_desc,
             "algorithmic_bytes_per_unit": 2.0 * n * esz,
             "units_per_launch_set": units_per_launch,
             "algorithmic_bytes_per_launch_set": 2.0 * n * esz * units_per_launch,
-            "launch_set_ms": ev_ms_per_step / n_groups,
+            "launch_set_ms": (per_pass[0]["avg_launch_ms"] if (team and per_pass) else ev_ms_per_step / n_groups),
             "per_pass": per_pass,
             "hip_event_ms_per_step": ev_ms_per_step,
             "note": "achieved = 2*N*sizeof(complex) bytes per transform x transforms per launch set / HIP-event duration "
-                    "of the set (events on the plan's stream, rank 0); per_pass = live HIP-event time of each pass kernel; "
+                    "of the set (events on the plan's stream, rank 0; team schedule: of the team_fft_kernel launch alone); per_pass = live "
+                    "HIP-event time of each launch; "
                     "traffic: " + traffic_note,
         },
         "check": check,

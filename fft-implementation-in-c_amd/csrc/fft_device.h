@@ -26,6 +26,7 @@ unsigned shfl_xor_u32(unsigned v, int mask);
 }  // namespace emu
 #define FFT_KERNEL
 #define FFT_DEVICE inline
+#define FFT_HOST_DEVICE inline
 #define FFT_TID ((int)emu::threadIdx_.x)
 #define FFT_BID ((long long)emu::blockIdx_.x)
 #define FFT_NTHREADS ((int)emu::blockDim_.x)
@@ -74,6 +75,7 @@ inline T shfl_xor_any(T v, int mask) {
 #include <hip/hip_runtime.h>
 #define FFT_KERNEL __global__
 #define FFT_DEVICE __device__ __forceinline__
+#define FFT_HOST_DEVICE __host__ __device__ __forceinline__
 #define FFT_TID ((int)threadIdx.x)
 #define FFT_BID ((long long)blockIdx.x)
 #define FFT_NTHREADS ((int)blockDim.x)

@@ -143,6 +143,7 @@ class Pow2Plan {
     const unsigned* run_if = nullptr;  // handed to the tile launches of the current execute (fallback mode)
     int team_pending = 0;        // team launches since the host last read the status word
     int team_fallbacks = 0;      // consecutive executes that ended in the two-pass fallback
+    int team_last_status = -1;   // what the host last read from the status word (-1: never launched)
     bool ok = false;
 
     ~Pow2Plan() { destroy(); }
@@ -163,7 +164,12 @@ class Pow2Plan {
 
     // ---- team kernel: geometry, tables, the L2-resident transposition windows, the control block
     void build_team(int batch) {
-        if (const char* e = getenv("FFT_HIP_TEAM")) if (atoi(e) == 0) return;
+        // FFT_HIP_TEAM: 0 never; 1 (default) where it measured faster than the two-pass schedule on MI355X -- fp32 with four
+        // tiles per workgroup (n = 2^20), 139 vs 126 Gpoint/s at batch 512; 2 every geometry the kernel is built for
+        // (fp32 n = 2^18..2^20, fp64 n = 2^17..2^19: those trail the two-pass schedule by 5-30 %)
+        int mode = 1;
+        if (const char* e = getenv("FFT_HIP_TEAM")) mode = atoi(e);
+        if (mode <= 0) return;
         TeamDesc<T> d;
         if (!rt->team_geometry(d.log2TS, d.n_teams, d.nthreads)) return;
         const int log2V = ilog2(V);
@@ -171,6 +177,7 @@ class Pow2Plan {
         const int log2NT = log2n - d.log2TS - log2TE;
         if (log2NT < 0 || log2NT > 2) return;  // the team's registers hold 1, 2 or 4 tiles per workgroup
         d.NT = 1 << log2NT;
+        if (mode == 1 && !(SZ == 8 && d.NT == 4)) return;
         d.log2L1 = log2n / 2;
         if (const char* e = getenv("FFT_HIP_TEAM_L1")) d.log2L1 = atoi(e);  // experiments / tests: force the split
         d.log2L2 = log2n - d.log2L1;
@@ -181,8 +188,8 @@ class Pow2Plan {
         const long long L1 = 1ll << d.log2L1, L2 = 1ll << d.log2L2;
         d.data_bytes = 2 * (SZ << log2TE);  // LDS-DMA landing image + work image, one tile each
         // tables: [sa1 | sb1 | sa2 | sb2 | t0 | t1]
-        d.sa1_bits = (L1 * SZ > 8192) ? (d.log2L1 + 1) / 2 : d.log2L1;
-        d.sa2_bits = (L2 * SZ > 8192) ? (d.log2L2 + 1) / 2 : d.log2L2;
+        d.sa1_bits = fftk::team_stage_table_bits(SZ, d.log2L1);
+        d.sa2_bits = fftk::team_stage_table_bits(SZ, d.log2L2);
         d.t0_bits = (log2n + 1) / 2;
         int ne = 1 << d.sa1_bits;
         d.o_sb1 = ne; ne += 1 << (d.log2L1 - d.sa1_bits);
@@ -220,7 +227,9 @@ class Pow2Plan {
             return;
         }
         rt->h2d(d.tables, blob.data(), blob.size() * SZ);
-        d.min_batch = d.n_teams;  // fewer transforms than teams leave XCDs idle: the two-pass plan spreads one transform over the chip
+        // Below ~32 transforms per team the launch's fixed costs (team formation, pipeline fill, the last transforms of
+        // uneven teams) outweigh the saved HBM round trip: measured crossover with the two-pass schedule at batch ~200.
+        d.min_batch = (mode == 1 ? 32 : 1) * d.n_teams;
         if (const char* e = getenv("FFT_HIP_TEAM_MIN_BATCH")) d.min_batch = atoi(e);
         (void)batch;
         d.ok = true;
@@ -276,6 +285,7 @@ class Pow2Plan {
         tp.seat_rot = seat_rot;
         static const int tile_rot = getenv("FFT_HIP_TEAM_TILE_ROT") ? atoi(getenv("FFT_HIP_TEAM_TILE_ROT")) : 4;
         tp.tile_rot = tile_rot;
+        tp.force_no_teams = getenv("FFT_HIP_TEAM_FORCE_FALLBACK") ? 1 : 0;  // tests: exercise the fallback on a healthy device
         tp.trace = team.trace;
         tp.trace_events = team.trace_events;
         tp.scale = scale;

@@ -184,18 +184,21 @@ struct DeviceGuard {
 // kernel in this plan / nothing launched.  Three fallbacks in a row switch the team kernel off for the plan.
 template <class Core>
 int team_status_of(Core* core) {
-    if (!core || !core->team.ok || !core->team_pending) return -1;
+    if (!core) return -1;
+    if (!core->team_pending) return core->team_last_status;  // nothing launched since the last look
+    if (!core->team.ctl) return -1;
     unsigned st = 0;
     if (hipMemcpy(&st, core->team.ctl + fftk::TEAM_CTL_STATUS, sizeof(st), hipMemcpyDeviceToHost) != hipSuccess) {
         (void)hipGetLastError();
         return -1;
     }
     core->team_pending = 0;
+    core->team_last_status = (int)st;
     if (st == fftk::TEAM_STATUS_NO_TEAMS) {
         if (++core->team_fallbacks >= 3) {
             fprintf(stderr, "fft_hip: the team kernel could not form its XCD teams three times in a row; this plan "
                             "continues with the two-pass schedule\n");
-            core->team.ok = false;
+            core->team.ok = false;  // the buffers stay allocated until the plan is destroyed
         }
     } else {
         core->team_fallbacks = 0;

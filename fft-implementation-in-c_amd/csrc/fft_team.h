@@ -66,6 +66,7 @@ struct TeamParams {
     int o_sb1, o_sa2, o_sb2, o_t0, o_t1;
     int sa1_bits, sa2_bits, t0_bits;
     long long timeout_ticks;  // bound of every spin, in FFT_CLOCK ticks
+    int force_no_teams;       // tests: pretend the placement check failed (exercises the two-pass fallback)
     int tile_rot;             // column_block(): seats rotate by this many blocks per tile
     int seat_rot;             // experiments: seat = (registration order + seat_rot) mod TS
     int dma_split;            // column-tile DMA: chunks [0, dma_split) go out after stage 1, the rest after stage 2
@@ -74,6 +75,11 @@ struct TeamParams {
     int trace_events;
     T scale;
 };
+
+// Low-level index bits of a stage twiddle table of a length-2^log2L sub-transform (log2L: single-level table).
+FFT_HOST_DEVICE int team_stage_table_bits(int elem_bytes, int log2L) {
+    return ((elem_bytes << log2L) > (elem_bytes == 16 ? 4096 : 8192)) ? (log2L + 1) / 2 : log2L;
+}
 
 // Has every member of the team stored generation `gen`?  On the device the first wavefront polls the team's
 // 128-byte flag line with ONE sc1 load (lane m reads member m's word); the emulation polls from one thread.
@@ -201,14 +207,16 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(512, 2) team_fft_kernel(TeamParams<T> p) {
     }
     const cpx<T>* tab = reinterpret_cast<const cpx<T>*>(tab_bytes);
     volatile unsigned* sh = reinterpret_cast<volatile unsigned*>(tab_bytes + p.tables_bytes);
-    StageTw<T> twA, twB;  // single-level stage table up to 8 KiB, else two-level (same rule as the planner)
+    // stage tables: single-level up to 8 KiB (fp32) / 4 KiB (fp64), else two-level -- TeamStageTable is the rule the
+    // planner lays the blob out by; decided from the (baked-in) geometry, so no per-lookup branch survives
+    StageTw<T> twA, twB;
     twA.sa = tab;
     twA.sb = tab + p.o_sb1;
-    twA.sa_bits = ((SZ << log2L1) > 8192) ? (log2L1 + 1) / 2 : log2L1;
+    twA.sa_bits = team_stage_table_bits(SZ, log2L1);
     twA.log2L = log2L1;
     twB.sa = tab + p.o_sa2;
     twB.sb = tab + p.o_sb2;
-    twB.sa_bits = ((SZ << log2L2) > 8192) ? (log2L2 + 1) / 2 : log2L2;
+    twB.sa_bits = team_stage_table_bits(SZ, log2L2);
     twB.log2L = log2L2;
 
     // ---- team formation: who shares my L2?
@@ -231,6 +239,7 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(512, 2) team_fft_kernel(TeamParams<T> p) {
                 if (cnt != (x < p.n_teams ? (unsigned)TS : 0u)) ok = 0;
             }
         }
+        if (p.force_no_teams) ok = 0;
         if (!ok) FFT_ATOMIC_STORE_AGENT(&p.ctl[TEAM_CTL_STATUS], (unsigned)TEAM_STATUS_NO_TEAMS);
         sh[0] = slot;
         sh[1] = xcc;

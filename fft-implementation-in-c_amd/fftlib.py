@@ -182,7 +182,7 @@ class Plan:
         self.lib.fft_gpu_plan_sync(self.handle)
 
     def team_status(self):
-        """0 team kernel did the last execute, 1 its fallback did, 2 barrier timeout, -1 no team kernel / nothing new."""
+        """0 team kernel did the last execute, 1 its fallback did, 2 barrier timeout, -1 no team kernel / never launched."""
         return self.lib.fft_gpu_plan_team_status_hip(self.handle)
 
     def timed(self, d_in, d_out, iters):

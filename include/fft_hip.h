@@ -103,7 +103,7 @@ int fft_gpu_execute_ptr_hip(fft_gpu_plan_t plan, const void* d_in, void* d_out);
 int fft_gpu_plan_sync_hip(fft_gpu_plan_t plan);
 /* syncs the plan's stream, then: 0 the last execute was done by the team kernel, 1 its XCD teams could not be
  * formed and the multi-pass fallback did the work, 2 a team barrier timed out (results invalid; plan_sync returns -1
- * too), -1 the plan has no team kernel or nothing was launched since the last query */
+ * too), -1 the plan has no team kernel or it has never been launched */
 int fft_gpu_plan_team_status_hip(fft_gpu_plan_t plan);
 /* profiling: every workgroup of the team kernel logs its 100 MHz clock at its first `events` timeline events into
  * d_trace[workgroup * events + i] (256 * events * 8 bytes of device memory owned by the caller); NULL switches it off */

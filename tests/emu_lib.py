@@ -59,6 +59,7 @@ def emu_fft_team(x, direction=-1, log2ts=2, n_teams=2, threads=16, lds_budget=0,
     """The team kernel (fft_team.h) with a small geometry: n_teams "XCDs" of 2^log2ts workgroups of `threads`
     threads, all running concurrently.  info[0] = 100*NT + passes when the team kernel was planned.
     skew=True makes workgroup 0 report the wrong XCD: the kernel must give up and the two-pass fallback run."""
+    os.environ["FFT_HIP_TEAM"] = "2"  # every geometry, any batch (the default only plans it where it measured faster)
     x = np.ascontiguousarray(x)
     prec = 1 if x.dtype == np.complex64 else 0
     batch, n = x.shape

@@ -105,3 +105,50 @@ def test_bit_reversal_kernel_emulated(golden):
     assert np.array_equal(out, want)
     E.lib().emu_bitrev(x.ctypes.data, x.ctypes.data, n, 2, 0)  # in place
     assert np.array_equal(x, want)
+
+
+# ---------------------------------------------------------------------------
+# team kernel (fft_team.h): a whole transform per "XCD", one HBM round trip.  The emulation runs EVERY workgroup of
+# the launch concurrently (one host thread per GPU thread, sequentially consistent memory), so it checks the index
+# algebra of the register/L2 hand-over AND the arrival/wait protocol between workgroups (a missing wait shows up as
+# a data race => wrong spectrum).  Geometries are scaled down: teams of 4 or 8 workgroups of 8..128 threads.
+# ---------------------------------------------------------------------------
+TEAM_CASES = [
+    # n, batch, dtype, log2ts, n_teams, threads, lds_budget   -> tiles per workgroup (NT), radix-16/8 stage count
+    (4096, 5, np.complex64, 2, 2, 16, 16384),    # NT 4 (two phases wait in registers), 64 x 64
+    (2048, 4, np.complex64, 2, 2, 16, 8192),     # NT 2, 32 x 64
+    (1024, 7, np.complex64, 3, 2, 8, 4096),      # NT 1, 32 x 32, teams of 8
+    (2048, 5, np.complex128, 2, 3, 16, 16384),   # fp64, three teams, ragged batch
+]
+
+
+@pytest.mark.parametrize("n,batch,dtype,log2ts,n_teams,threads,lds", TEAM_CASES)
+def test_team_kernel(n, batch, dtype, log2ts, n_teams, threads, lds):
+    x = O.gen_lcg(n, 1, batch).astype(dtype)
+    for d in (-1, 1):
+        for inplace in (False, True):
+            y, info = E.emu_fft_team(x, d, log2ts=log2ts, n_teams=n_teams, threads=threads, lds_budget=lds, inplace=inplace)
+            assert info[0] >= 100, "team kernel was not planned"
+            assert rel(y, oracle(x, d)) < TOL[dtype], (n, d, inplace)
+
+
+def test_team_kernel_fallback_when_teams_cannot_form():
+    """Workgroup 0 reports the wrong XCD: no launch yields full teams, the kernel must give up before touching
+    anything and the two-pass schedule queued behind it must produce the result (also in place)."""
+    x = O.gen_lcg(4096, 2, 3).astype(np.complex64)
+    for inplace in (False, True):
+        y, info = E.emu_fft_team(x, -1, log2ts=2, n_teams=2, threads=16, lds_budget=16384, inplace=inplace, skew=True)
+        assert info[0] >= 100
+        assert rel(y, oracle(x, -1)) < TOL[np.complex64]
+
+
+@pytest.mark.parametrize("dtype,threads", [(np.complex64, 64), (np.complex128, 128)])
+def test_team_kernel_three_stage_rows(dtype, threads, monkeypatch):
+    """32 x 512 split: the row FFTs have three stages, so the hand-over of phase ph+2 and the next tile's DMA are
+    issued from two different mid-stage hooks (the shape of the production geometry, 1024 = 16 x 16 x 4)."""
+    monkeypatch.setenv("FFT_HIP_TEAM_L1", "5")
+    x = O.gen_lcg(1 << 14, 4, 5).astype(dtype)
+    for d, inplace in ((-1, False), (1, True)):
+        y, info = E.emu_fft_team(x, d, log2ts=2, n_teams=2, threads=threads, lds_budget=65536, inplace=inplace)
+        assert info[0] >= 400
+        assert rel(y, oracle(x, d)) < TOL[dtype]

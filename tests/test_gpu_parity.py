@@ -457,3 +457,117 @@ def test_full_size_config4_shard_and_config5(gpu_lib):
     inv.execute(d, d)
     assert rel(d.download(x.shape, x.dtype), x) <= 1e-6
     fwd.destroy(); inv.destroy(); d.free()
+
+
+# ---------------------------------------------------------------------------
+# team kernel (csrc/fft_team.h): a whole transform per XCD, one HBM round trip.  FFT_HIP_TEAM=2 plans it for every
+# geometry it is built for and any batch (the default policy only uses it where it measured faster: fp32 n = 2^20,
+# batch >= 256), so that all six instantiations are parity-checked on the device.
+# ---------------------------------------------------------------------------
+def _team_plan(monkeypatch, n, batch, direction, dtype, mode="2"):
+    import fftlib
+    monkeypatch.setenv("FFT_HIP_TEAM", mode)
+    plan = fftlib.Plan(n, batch, direction, dtype)
+    return plan
+
+
+@pytest.mark.parametrize("log2n,dtype,tiles", [(20, np.complex64, 4), (19, np.complex64, 2), (18, np.complex64, 1),
+                                               (19, np.complex128, 4), (18, np.complex128, 2), (17, np.complex128, 1)])
+def test_team_kernel_vs_oracle(gpu_lib, monkeypatch, log2n, dtype, tiles):
+    import fftlib
+    n, batch = 1 << log2n, 19  # ragged: 19 transforms over 8 teams
+    x = lcg(n, batch, dtype, seed=log2n)
+    buf = fftlib.DeviceBuffer(x.nbytes)
+    out = fftlib.DeviceBuffer(x.nbytes)
+    for d in (-1, 1):
+        plan = _team_plan(monkeypatch, n, batch, d, dtype)
+        assert plan.info().team_tiles == tiles
+        buf.upload(x)
+        out.upload(np.full_like(x, np.nan))
+        plan.execute_ptr(buf.ptr, out.ptr)
+        assert plan.team_status() == 0, "the team kernel must have done the work (teams formed, no timeout)"
+        y = out.download(x.shape, dtype)
+        for b in (0, 7, 8, batch - 1):
+            ref = O.oracle_fft(x[b:b + 1].astype(np.complex128), d, "dit")
+            r = rel(y[b:b + 1], ref)
+            assert r <= TOL[np.dtype(dtype)] and r <= TIGHT[np.dtype(dtype)], (log2n, d, b, r)
+        # in place, and bit-identical to out of place
+        plan.execute_ptr(buf.ptr, buf.ptr)
+        assert plan.team_status() == 0
+        assert np.array_equal(buf.download(x.shape, dtype), y)
+        # the multi-pass schedule computes the same spectrum
+        monkeypatch.setenv("FFT_HIP_TEAM", "0")
+        plan2 = fftlib.Plan(n, batch, d, dtype)
+        assert plan2.info().team_tiles == 0
+        buf.upload(x)
+        plan2.execute_ptr(buf.ptr, out.ptr)
+        plan2.sync()
+        assert rel(out.download(x.shape, dtype), y) <= (1e-6 if dtype == np.complex64 else 1e-14)
+        plan.destroy()
+        plan2.destroy()
+    buf.free()
+    out.free()
+
+
+def test_team_kernel_default_policy_and_full_size(gpu_lib, monkeypatch):
+    """BASELINE configs[2] as bench.py runs it: N = 2^20 fp32 x 512 takes the team kernel by default; every one of
+    the 512 spectra is checked against the analytic two-tone answer; a batch of 64 keeps the two-pass schedule."""
+    import fftlib
+    monkeypatch.delenv("FFT_HIP_TEAM", raising=False)
+    n, batch = 1 << 20, 512
+    small = fftlib.Plan(n, 64, -1, np.complex64)
+    assert small.info().team_tiles == 4  # planned ...
+    xs = lcg(n, 64, np.complex64, seed=5)
+    bs = fftlib.DeviceBuffer(xs.nbytes)
+    bs.upload(xs)
+    small.execute_ptr(bs.ptr, bs.ptr)
+    assert small.team_status() == -1  # ... but not launched below the crossover batch
+    small.destroy()
+    bs.free()
+    plan = fftlib.Plan(n, batch, -1, np.complex64)
+    x = O.gen_two_tone(n, 0, batch, np.complex64)
+    buf = fftlib.DeviceBuffer(x.nbytes)
+    buf.upload(x)
+    plan.execute_ptr(buf.ptr, buf.ptr)
+    assert plan.team_status() == 0
+    y = buf.download(x.shape, np.complex64)
+    bb = np.arange(batch, dtype=np.int64)
+    f = (1 + 7 * bb) % n
+    g = (n // 3 + 13 * bb) % n
+    g = np.where(g == f, (g + 1) % n, g)
+    rows = np.arange(batch)
+    assert np.abs(y[rows, f] - n).max() / n < 1e-4
+    assert np.abs(y[rows, g] - n / 2).max() / n < 1e-4
+    want = n * 1.25 ** 0.5
+    for s in range(0, batch, 32):  # Parseval, 32 transforms at a time (fp64 accumulation without a 9 GB temporary)
+        tot = np.linalg.norm(y[s:s + 32].astype(np.complex128), axis=1)
+        assert np.abs(tot - want).max() / want < 1e-4
+    # inverse of the forward result returns the input (round trip at full size)
+    inv = fftlib.Plan(n, batch, 1, np.complex64)
+    inv.execute_ptr(buf.ptr, buf.ptr)
+    assert inv.team_status() == 0
+    assert rel(buf.download(x.shape, np.complex64), x) < 1e-5
+    plan.destroy()
+    inv.destroy()
+    buf.free()
+
+
+def test_team_kernel_fallback_on_device(gpu_lib, monkeypatch):
+    """FFT_HIP_TEAM_FORCE_FALLBACK makes the kernel's placement check fail on a healthy device: status 1, nothing
+    touched by the team kernel, the two-pass launches queued behind it deliver the (in-place) result; after three
+    fallbacks in a row the plan stops launching the team kernel."""
+    import fftlib
+    monkeypatch.setenv("FFT_HIP_TEAM_FORCE_FALLBACK", "1")
+    n, batch = 1 << 20, 16
+    plan = _team_plan(monkeypatch, n, batch, -1, np.complex64)
+    x = lcg(n, batch, np.complex64, seed=9)
+    buf = fftlib.DeviceBuffer(x.nbytes)
+    ref = O.oracle_fft(x[:2].astype(np.complex128), -1, "dit")
+    for it in range(4):
+        buf.upload(x)
+        plan.execute_ptr(buf.ptr, buf.ptr)
+        st = plan.team_status()
+        assert st == 1, (it, st)  # the fourth execute no longer launches the team kernel: last known status stays 1
+        assert rel(buf.download(x.shape, np.complex64)[:2], ref) <= TIGHT[np.dtype(np.complex64)]
+    plan.destroy()
+    buf.free()

@@ -22,6 +22,7 @@ def main():
     batch = int(sys.argv[2]) if len(sys.argv) > 2 else 64
     dtype = np.complex64 if (len(sys.argv) <= 3 or sys.argv[3] == "f32") else np.complex128
     n = 1 << log2n
+    os.environ.setdefault("FFT_HIP_TEAM", "2")  # every geometry the team kernel is built for, any batch
     fftlib.init()
     x = O.gen_lcg(n, 3, batch).astype(dtype)
     buf_in = fftlib.DeviceBuffer(x.nbytes)
@@ -41,7 +42,7 @@ def main():
         y = buf_out.download(x.shape, dtype)
         os.environ["FFT_HIP_TEAM"] = "0"
         plan2 = fftlib.Plan(n, batch, direction, dtype)
-        del os.environ["FFT_HIP_TEAM"]
+        os.environ["FFT_HIP_TEAM"] = "2"
         assert plan2.info().team_tiles == 0
         buf_out.upload(poison)
         plan2.execute_ptr(buf_in.ptr, buf_out.ptr)

@@ -32,7 +32,8 @@ def main():
     fftlib.init()
     x = O.gen_lcg(n, 3, 8).astype(np.complex64)
     x = np.tile(x, (batch // 8, 1))
-    buf = fftlib.DeviceBuffer(x.nbytes)
+    in_off = int(os.environ.get("TEAM_IN_OFF", "0"))  # experiment: shift the input by this many bytes
+    buf = fftlib.DeviceBuffer(x.nbytes + 8192)
     out = fftlib.DeviceBuffer(x.nbytes)
     buf.upload(x)
     plan = fftlib.Plan(n, batch, -1, np.complex64)
@@ -41,11 +42,11 @@ def main():
     events = 2 + per * 6
     tr = fftlib.DeviceBuffer(256 * events * 8)
     tr.upload(np.zeros(256 * events, dtype=np.int64))
-    plan.timed(buf.ptr, out.ptr, 3)
-    ms = plan.timed(buf.ptr, out.ptr, 10) / 10
+    plan.timed((buf.ptr + in_off), out.ptr, 3)
+    ms = plan.timed((buf.ptr + in_off), out.ptr, 10) / 10
     print("batch %d: %.3f ms = %.1f Gpoint/s (%.1f us per transform per team)" % (batch, ms, n * batch / ms / 1e6, ms * 1e3 / (batch / 8)))
     plan.lib.fft_gpu_plan_team_trace_hip(plan.handle, tr.ptr, events)
-    plan.execute_ptr(buf.ptr, out.ptr)
+    plan.execute_ptr((buf.ptr + in_off), out.ptr)
     print("status", plan.team_status())
     t = tr.download((256, events), np.int64).astype(np.float64) / 100.0  # us
     t0 = t[:, 0].min()
