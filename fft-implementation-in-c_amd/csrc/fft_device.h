@@ -70,6 +70,8 @@ inline T shfl_xor_any(T v, int mask) {
 #define FFT_LDS_ADDR(ptr) 0u
 #define FFT_DMA16(gsrc, lds_base_ptr, lds_base_addr, off) memcpy((lds_base_ptr) + (off), (gsrc), 16)
 #define FFT_DMA16_L2(gsrc, lds_base_ptr, lds_base_addr, off) memcpy((lds_base_ptr) + (off), (gsrc), 16)
+#define FFT_DMA16_NT(gsrc, lds_base_ptr, lds_base_addr, off) memcpy((lds_base_ptr) + (off), (gsrc), 16)
+#define FFT_STORE16_NT(ptr, v) (*(ptr) = (v))
 #define FFT_WAIT_VM_LE8() __atomic_thread_fence(__ATOMIC_SEQ_CST)
 #else
 #include <hip/hip_runtime.h>
@@ -130,6 +132,17 @@ inline T shfl_xor_any(T v, int mask) {
 #define FFT_LDS_ADDR(ptr) ((unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(ptr))
 #define FFT_DMA16(gsrc, lds_base_ptr, lds_base_addr, off) fft_dma16<0>((gsrc), (lds_base_addr) + (unsigned)(off))
 #define FFT_DMA16_L2(gsrc, lds_base_ptr, lds_base_addr, off) fft_dma16<1>((gsrc), (lds_base_addr) + (unsigned)(off))
+#define FFT_DMA16_NT(gsrc, lds_base_ptr, lds_base_addr, off) fft_dma16<2>((gsrc), (lds_base_addr) + (unsigned)(off))
+// 16-byte store with the non-temporal (streaming) hint: the line is the first to leave the L2
+#define FFT_STORE16_NT(ptr, v) fft_store16_nt((ptr), (v))
+typedef unsigned fft_u32x4 __attribute__((ext_vector_type(4)));
+template <class V16>
+__device__ __forceinline__ void fft_store16_nt(V16* ptr, const V16& v) {
+    static_assert(sizeof(V16) == 16, "one 16-byte lane access");
+    fft_u32x4 raw;
+    __builtin_memcpy(&raw, &v, 16);
+    __builtin_nontemporal_store(raw, reinterpret_cast<fft_u32x4*>(ptr));
+}
 #define FFT_WAIT_VM_LE8() asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
 template <int SC1>
 __device__ __forceinline__ void fft_dma16(const void* gsrc, unsigned lane_lds_addr) {
@@ -137,8 +150,11 @@ __device__ __forceinline__ void fft_dma16(const void* gsrc, unsigned lane_lds_ad
     // M0 = LDS byte address of the wave's first lane; the hardware adds 16 * lane
     const unsigned lds_addr = __builtin_amdgcn_readfirstlane(lane_lds_addr);
     unsigned saved_m0;
-    if (SC1)
+    if (SC1 == 1)
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off sc1\n\ts_mov_b32 m0, %0"
+                     : "=&s"(saved_m0) : "v"(gsrc), "s"(lds_addr) : "memory");
+    else if (SC1 == 2)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
                      : "=&s"(saved_m0) : "v"(gsrc), "s"(lds_addr) : "memory");
     else
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"

@@ -285,6 +285,8 @@ class Pow2Plan {
         tp.seat_rot = seat_rot;
         static const int tile_rot = getenv("FFT_HIP_TEAM_TILE_ROT") ? atoi(getenv("FFT_HIP_TEAM_TILE_ROT")) : 4;
         tp.tile_rot = tile_rot;
+        static const int nt_mask = getenv("FFT_HIP_TEAM_NT") ? atoi(getenv("FFT_HIP_TEAM_NT")) : 0;
+        tp.nt_mask = nt_mask;
         tp.force_no_teams = getenv("FFT_HIP_TEAM_FORCE_FALLBACK") ? 1 : 0;  // tests: exercise the fallback on a healthy device
         tp.trace = team.trace;
         tp.trace_events = team.trace_events;

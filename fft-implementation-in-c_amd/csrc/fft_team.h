@@ -66,6 +66,7 @@ struct TeamParams {
     int o_sb1, o_sa2, o_sb2, o_t0, o_t1;
     int sa1_bits, sa2_bits, t0_bits;
     long long timeout_ticks;  // bound of every spin, in FFT_CLOCK ticks
+    int nt_mask;              // cache policy of the HBM streams: bit 0 column-tile DMA nt, bit 1 result stores nt
     int force_no_teams;       // tests: pretend the placement check failed (exercises the two-pass fallback)
     int tile_rot;             // column_block(): seats rotate by this many blocks per tile
     int seat_rot;             // experiments: seat = (registration order + seat_rot) mod TS
@@ -301,7 +302,10 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(512, 2) team_fft_kernel(TeamParams<T> p) {
         const long long step = (long long)(nthreads >> log2CPR) << log2L2;  // rows per wave-front of chunks
         FFT_UNROLL
         for (int i = 0; i < 8; i++)
-            if (i >= i0 && i < i1) FFT_DMA16(src + i * step, land, land_lds, (unsigned)(i * nthreads + tid) * 16u);
+            if (i >= i0 && i < i1) {
+                if (p.nt_mask & 1) FFT_DMA16_NT(src + i * step, land, land_lds, (unsigned)(i * nthreads + tid) * 16u);
+                else FFT_DMA16(src + i * step, land, land_lds, (unsigned)(i * nthreads + tid) * 16u);
+            }
     };
     // LDS-DMA of my row tile of the window `sb` (tile_bytes contiguous bytes), served by the XCD's L2
     auto dma_row_tile = [&](const unsigned char* sb) __attribute__((always_inline)) {
@@ -480,7 +484,9 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(512, 2) team_fft_kernel(TeamParams<T> p) {
                     const long long K = rB + (((2 * q) + (odd ? 1 : 0)) << log2TPCB);
                     vec16<T> v;
                     pair_rows<T>(x[0][2 * q][0], x[0][2 * q + 1][0], odd, 1, v);
-                    *reinterpret_cast<vec16<T>*>(outb + (K << log2L1) + k1 + (jB & ~1)) = v;
+                    vec16<T>* dst = reinterpret_cast<vec16<T>*>(outb + (K << log2L1) + k1 + (jB & ~1));
+                    if (p.nt_mask & 2) FFT_STORE16_NT(dst, v);
+                    else *dst = v;
                 }
             } else {
                 FFT_UNROLL
