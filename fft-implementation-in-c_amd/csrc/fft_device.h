@@ -72,7 +72,7 @@ inline T shfl_xor_any(T v, int mask) {
 #define FFT_DMA16_L2(gsrc, lds_base_ptr, lds_base_addr, off) memcpy((lds_base_ptr) + (off), (gsrc), 16)
 #define FFT_DMA16_NT(gsrc, lds_base_ptr, lds_base_addr, off) memcpy((lds_base_ptr) + (off), (gsrc), 16)
 #define FFT_STORE16_NT(ptr, v) (*(ptr) = (v))
-#define FFT_WAIT_VM_LE8() __atomic_thread_fence(__ATOMIC_SEQ_CST)
+#define FFT_WAIT_VM_LE(n) __atomic_thread_fence(__ATOMIC_SEQ_CST)
 #else
 #include <hip/hip_runtime.h>
 #define FFT_KERNEL __global__
@@ -125,7 +125,7 @@ inline T shfl_xor_any(T v, int mask) {
 // passes ldst = base + 16 * lane-linear index.  aux: 0 default, 2 nt, 16 sc1 (bypass the vector L1).  Counts in vmcnt.
 // Hand-issued LDS-DMA (inline asm): hipcc does not see it, so it neither counts it in its own s_waitcnt bookkeeping
 // (its waits only get stricter: vmcnt is in order) nor drains it in front of LDS reads that "may alias" -- the kernel
-// waits for its DMA itself (FFT_WAIT_VM0 / FFT_WAIT_VM_LE8 + barrier) before anybody reads the landing image.
+// waits for its DMA itself (FFT_WAIT_VM0 / FFT_WAIT_VM_LE + barrier) before anybody reads the landing image.
 //   FFT_DMA16     from HBM, default cache policy        FFT_DMA16_L2  sc1: served by the XCD's L2, never the vector L1
 //   FFT_LDS_ADDR  the 32-bit LDS byte address of a __shared__ pointer (taken once per kernel)
 // `off` is the byte offset of THIS lane's 16 bytes from the image base; the wave's first lane gives M0.
@@ -143,7 +143,7 @@ __device__ __forceinline__ void fft_store16_nt(V16* ptr, const V16& v) {
     __builtin_memcpy(&raw, &v, 16);
     __builtin_nontemporal_store(raw, reinterpret_cast<fft_u32x4*>(ptr));
 }
-#define FFT_WAIT_VM_LE8() asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
+#define FFT_WAIT_VM_LE(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")  // at most n of my memory operations still in flight
 template <int SC1>
 __device__ __forceinline__ void fft_dma16(const void* gsrc, unsigned lane_lds_addr) {
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -111,6 +111,7 @@ template <typename T>
 struct TeamDesc {
     bool ok = false;
     int log2L1 = 0, log2L2 = 0, log2CA = 0, log2CB = 0, log2TS = 0, n_teams = 0, NT = 0, nthreads = 0;
+    int E = 0;  // elements per thread = stage radix (fp32: 16 -> 512 threads, 8 -> 1024 threads; fp64: 8)
     int data_bytes = 0, tables_elems = 0, smem_bytes = 0;
     int o_sb1 = 0, o_sa2 = 0, o_sb2 = 0, o_t0 = 0, o_t1 = 0, sa1_bits = 0, sa2_bits = 0, t0_bits = 0;
     int min_batch = 1;
@@ -174,6 +175,13 @@ class Pow2Plan {
         if (!rt->team_geometry(d.log2TS, d.n_teams, d.nthreads)) return;
         const int log2V = ilog2(V);
         const int log2TE = ilog2(d.nthreads) + 3 + log2V;  // elements of a tile: threads * 8 lane accesses of V elements
+        // elements per thread: 8 * V (radix-16 stages for fp32) by default; fp32 can also run 8 per thread on twice the
+        // threads (radix-8 stages, 4 waves per SIMD) -- FFT_HIP_TEAM_E
+        d.E = 8 * V;
+        if (V == 2) {
+            static const int e_pref = getenv("FFT_HIP_TEAM_E") ? atoi(getenv("FFT_HIP_TEAM_E")) : 16;
+            if (e_pref == 8) { d.E = 8; d.nthreads *= 2; }
+        }
         const int log2NT = log2n - d.log2TS - log2TE;
         if (log2NT < 0 || log2NT > 2) return;  // the team's registers hold 1, 2 or 4 tiles per workgroup
         d.NT = 1 << log2NT;
@@ -184,7 +192,8 @@ class Pow2Plan {
         d.log2CA = log2TE - d.log2L1;
         d.log2CB = log2TE - d.log2L2;
         // a thread holds 8 * V elements of one column; fp32 pairs the lanes of adjacent rows for its 16-byte stores
-        if (d.log2L1 < 3 + log2V + log2V || d.log2L2 < 3 + log2V || d.log2CA < log2V || d.log2CB < log2V || d.log2CA > 5) return;
+        const int log2E = ilog2(d.E);
+        if (d.log2L1 < log2E + log2V || d.log2L2 < log2E || d.log2CA < log2V || d.log2CB < log2V || d.log2CA > 5) return;
         const long long L1 = 1ll << d.log2L1, L2 = 1ll << d.log2L2;
         d.data_bytes = 2 * (SZ << log2TE);  // LDS-DMA landing image + work image, one tile each
         // tables: [sa1 | sb1 | sa2 | sb2 | t0 | t1]
@@ -236,16 +245,22 @@ class Pow2Plan {
         team = d;
     }
 
-    template <int NT>
-    void launch_team_nt(const fftk::TeamParams<T>& tp) {
+    template <int NT, int E>
+    void launch_team_nt_e(const fftk::TeamParams<T>& tp) {
         const long long grid = (long long)team.n_teams << team.log2TS;
 #if defined(FFT_EMU)
-        rt->launch_coresident(fftk::team_fft_kernel<T, NT, 0>, grid, team.nthreads, (size_t)team.smem_bytes, tp);
+        rt->launch_coresident(fftk::team_fft_kernel<T, NT, E, 0>, grid, team.nthreads, (size_t)team.smem_bytes, tp);
 #else
         // the device instantiations have their geometry baked in (fft_team_list.h)
         constexpr int GEO = fftk::TeamGeo<T, NT>::value;
-        rt->launch_coresident(fftk::team_fft_kernel<T, NT, GEO>, grid, team.nthreads, (size_t)team.smem_bytes, tp);
+        rt->launch_coresident(fftk::team_fft_kernel<T, NT, E, GEO>, grid, team.nthreads, (size_t)team.smem_bytes, tp);
 #endif
+    }
+
+    template <int NT>
+    void launch_team_nt(const fftk::TeamParams<T>& tp) {
+        if (V == 2 && team.E == 8) launch_team_nt_e<NT, (V == 2 ? 8 : 8 * V)>(tp);
+        else launch_team_nt_e<NT, 8 * V>(tp);
     }
 
     bool team_geometry_is_built() const {

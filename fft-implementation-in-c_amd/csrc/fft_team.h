@@ -166,12 +166,15 @@ FFT_DEVICE void pair_rows(cpx<T> own_s0, cpx<T> own_s1, bool odd, int mask, vec1
 //   the next transform's hand-over of phases 0, 1 needs everybody's last reads: aNT of this transform
 // NT = tiles per workgroup per step = n / (TS * tile elements); GEO != 0 bakes the geometry into the instantiation.
 // ---------------------------------------------------------------------------
-template <typename T, int NT, int GEO>
-FFT_KERNEL void FFT_LAUNCH_BOUNDS2(512, 2) team_fft_kernel(TeamParams<T> p) {
+// E = elements per thread, all of ONE column = the radix of the stages.  A tile is 64 KiB (4096 * V16 elements), so the
+// workgroup has 4096 * V16 / E threads: fp32 E = 16 -> 512 threads (2 waves per SIMD), E = 8 -> 1024 threads (4 waves per
+// SIMD: one more LDS exchange per tile, twice the waves to hide LDS latency and barriers behind); fp64 E = 8 -> 512.
+template <typename T, int NT, int E, int GEO>
+FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E) team_fft_kernel(TeamParams<T> p) {
     constexpr int V16 = vec16<T>::V;  // complex values per 16-byte lane access of HBM / L2: 2 (fp32) or 1 (fp64)
     constexpr int log2V16 = Log2<V16>::value;
-    constexpr int E = 8 * V16;        // elements per thread, all of ONE column: radix-16 (fp32) / radix-8 (fp64) stages
     constexpr int log2E = Log2<E>::value;
+    constexpr int NCH = E / V16;      // 16-byte chunks of a tile per thread (LDS-DMA instructions, result stores)
     constexpr int SZ = (int)sizeof(cpx<T>);
     constexpr int EP = E / NT;                     // register slots (rows r + TPC*e) that one phase hands over
     constexpr int NK = NT > 2 ? NT - 2 : 0;        // phases whose hand-over waits in registers (phases 0, 1 go out at once)
@@ -301,7 +304,7 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(512, 2) team_fft_kernel(TeamParams<T> p) {
         const cpx<T>* src = inb + ((long long)(tid >> log2CPR) << log2L2) + c0 + V16 * (tid & ((1 << log2CPR) - 1));
         const long long step = (long long)(nthreads >> log2CPR) << log2L2;  // rows per wave-front of chunks
         FFT_UNROLL
-        for (int i = 0; i < 8; i++)
+        for (int i = 0; i < NCH; i++)
             if (i >= i0 && i < i1) {
                 if (p.nt_mask & 1) FFT_DMA16_NT(src + i * step, land, land_lds, (unsigned)(i * nthreads + tid) * 16u);
                 else FFT_DMA16(src + i * step, land, land_lds, (unsigned)(i * nthreads + tid) * 16u);
@@ -313,7 +316,7 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(512, 2) team_fft_kernel(TeamParams<T> p) {
         FFT_OPAQUE(tid);
         const unsigned char* src = sb + (size_t)c * tile_bytes + (size_t)tid * 16;
         FFT_UNROLL
-        for (int i = 0; i < 8; i++)
+        for (int i = 0; i < NCH; i++)
             FFT_DMA16_L2(src + (size_t)i * nthreads * 16, land, land_lds, (unsigned)(i * nthreads + tid) * 16u);
     };
     // Hand over the EP values y[] (rows rA + TPCA*ee of the phase, column c0 + jA) into window `sb`.  Row cp*CB + i of
@@ -346,7 +349,7 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(512, 2) team_fft_kernel(TeamParams<T> p) {
     for (int b = team; b < p.nb; b += p.n_teams, g0 += NARR) {
         const cpx<T>* inb = p.in + (long long)b * n;
         cpx<T>* outb = p.out + (long long)b * n;
-        if (!have_first) dma_column_tile(inb, 0, 0, 8);
+        if (!have_first) dma_column_tile(inb, 0, 0, NCH);
 
         // ================= step A: L2-strided column FFTs of length L1; phases 0, 1 are handed over at once
         FFT_NOUNROLL
@@ -365,15 +368,15 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(512, 2) team_fft_kernel(TeamParams<T> p) {
                     if (more) {
                         if (total >= 3) {
                             if (s == 0) dma_column_tile(inb, t + 1, 0, p.dma_split);
-                            if (s == 1) dma_column_tile(inb, t + 1, p.dma_split, 8);
+                            if (s == 1) dma_column_tile(inb, t + 1, p.dma_split, NCH);
                         } else if (s == 0) {
-                            dma_column_tile(inb, t + 1, 0, 8);
+                            dma_column_tile(inb, t + 1, 0, NCH);
                         }
                     }
                 }, p.inverse != 0);  // inverse = forward transform between two re<->im swaps: first one here
             } else if (more) {
                 FFT_SYNC_LDS();
-                dma_column_tile(inb, t + 1, 0, 8);
+                dma_column_tile(inb, t + 1, 0, NCH);
             }
             if (!(p.ablate & 1)) {  // W_n^(k1 n2), two-level LDS table
                 const cpx<T>* t0 = tab + p.o_t0;
@@ -433,7 +436,7 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(512, 2) team_fft_kernel(TeamParams<T> p) {
                         if (ph >= 1) wait_all(g0 + ph + 1);  // everybody's hand-over of phase ph+1 (a0 covers phase 1)
                         dma_row_tile(sbase + (size_t)((ph + 1) & 1) * phase_bytes);
                     } else if (next_transform) {
-                        dma_column_tile(inb + (long long)p.n_teams * n, 0, 0, 8);
+                        dma_column_tile(inb + (long long)p.n_teams * n, 0, 0, NCH);
                     }
                 }
                 // hand-over of phase ph+2: as early as its wait allows, so that the stores are long in L2 when the phase
@@ -497,9 +500,9 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(512, 2) team_fft_kernel(TeamParams<T> p) {
             }
             ev();  // B: result stores issued
             if (ph + 1 < NT) {
-                // everything but my 8 result stores is complete: the next row tile has landed, my hand-over of phase
+                // everything but my NCH result stores is complete: the next row tile has landed, my hand-over of phase
                 // ph+2 is in L2
-                FFT_WAIT_VM_LE8();
+                FFT_WAIT_VM_LE(NCH);
                 FFT_SYNC_LDS();
                 arrive(g0 + ph + 2);  // a(ph+2)
                 ev();  // B: phase closed
