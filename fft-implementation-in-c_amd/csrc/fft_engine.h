@@ -302,6 +302,8 @@ class Pow2Plan {
         tp.tile_rot = tile_rot;
         static const int nt_mask = getenv("FFT_HIP_TEAM_NT") ? atoi(getenv("FFT_HIP_TEAM_NT")) : 0;
         tp.nt_mask = nt_mask;
+        static const int tune = getenv("FFT_HIP_TEAM_TUNE") ? atoi(getenv("FFT_HIP_TEAM_TUNE")) : 0;
+        tp.tune = tune;
         tp.force_no_teams = getenv("FFT_HIP_TEAM_FORCE_FALLBACK") ? 1 : 0;  // tests: exercise the fallback on a healthy device
         tp.trace = team.trace;
         tp.trace_events = team.trace_events;

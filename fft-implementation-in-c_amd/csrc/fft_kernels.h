@@ -123,7 +123,13 @@ struct StageTw {
 struct StageNoHook {
     FFT_DEVICE void operator()() const {}
 };
-template <typename T, int E, int R, int V, int H, class Hook>
+// SWZ: bit 0 the inputs are read from, bit 1 the outputs are written to, positions idx ^ ((idx >> 2) & 3) instead of
+// idx.  A final radix-4 stage reads elements 4u .. 4u+3 per butterfly: four threads u of a lane group then sit on the
+// same banks (4-way conflict, a quarter of all LDS cycles of the team kernel); the XOR spreads them, and the stage
+// before writes through the same map (its 16-lane write groups stay conflict-free).
+FFT_DEVICE int stage_swizzle(int idx) { return idx ^ ((idx >> 2) & 3); }
+
+template <typename T, int E, int R, int V, int H, int SWZ = 0, class Hook>
 FFT_DEVICE void stockham_stage_rw(cpx<T> (&x)[H][E][V], const unsigned char* smem_rd, unsigned char* smem, int group_bytes,
                                   const StageTw<T>& tw, int r, int j, int log2J, int log2TPC, int& log2Lprev, int& log2P,
                                   bool first, bool last, Hook&& after_read, bool swap_in = false);
@@ -135,7 +141,7 @@ FFT_DEVICE void stockham_stage(cpx<T> (&x)[H][E][V], unsigned char* smem, int gr
                                      StageNoHook());
 }
 
-template <typename T, int E, int R, int V, int H, class Hook>
+template <typename T, int E, int R, int V, int H, int SWZ, class Hook>
 FFT_DEVICE void stockham_stage_rw(cpx<T> (&x)[H][E][V], const unsigned char* smem_rd, unsigned char* smem, int group_bytes,
                                   const StageTw<T>& tw, int r, int j, int log2J, int log2TPC, int& log2Lprev, int& log2P,
                                   bool first, bool last, Hook&& after_read, bool swap_in) {
@@ -158,7 +164,8 @@ FFT_DEVICE void stockham_stage_rw(cpx<T> (&x)[H][E][V], const unsigned char* sme
                 const int base = (kp << log2Lprev) + q;
                 FFT_UNROLL
                 for (int a = 0; a < R; a++) {
-                    lvec<T, V> v = data[((base + (a << log2Li)) << log2J) + j];
+                    const int idx_in = base + (a << log2Li);
+                    lvec<T, V> v = data[(((SWZ & 1) ? stage_swizzle(idx_in) : idx_in) << log2J) + j];
                     FFT_UNROLL
                     for (int vv = 0; vv < V; vv++) x[h][m + G * a][vv] = v.c[vv];
                 }
@@ -226,7 +233,7 @@ FFT_DEVICE void stockham_stage_rw(cpx<T> (&x)[H][E][V], const unsigned char* sme
                     FFT_UNROLL
                     for (int vv = 0; vv < V; vv++) v.c[vv] = x[h][m + G * k][vv];
                     const int idx = ((kp + (k << log2P)) << log2Li) + q;
-                    data[(idx << log2J) + j] = v;
+                    data[(((SWZ & 2) ? stage_swizzle(idx) : idx) << log2J) + j] = v;
                 }
             }
         }

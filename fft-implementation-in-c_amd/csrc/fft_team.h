@@ -66,6 +66,7 @@ struct TeamParams {
     int o_sb1, o_sa2, o_sb2, o_t0, o_t1;
     int sa1_bits, sa2_bits, t0_bits;
     long long timeout_ticks;  // bound of every spin, in FFT_CLOCK ticks
+    int tune;                 // experiments: bit 0 hand-over of phase 2 from the first hook of phase 0 too
     int nt_mask;              // cache policy of the HBM streams: bit 0 column-tile DMA nt, bit 1 result stores nt
     int force_no_teams;       // tests: pretend the placement check failed (exercises the two-pass fallback)
     int tile_rot;             // column_block(): seats rotate by this many blocks per tile
@@ -123,15 +124,24 @@ FFT_DEVICE void team_all_stages(cpx<T> (&x)[1][E][1], const unsigned char* land,
     const int n_full = log2L / log2E;
     const int rem = log2L - n_full * log2E;
     const int total = n_full + (rem ? 1 : 0);
+    // a final radix-4 stage reads through the bank swizzle (stage_swizzle), the exchange before it writes through it
+    const bool swz = (rem == 2) && n_full >= 2 && sizeof(cpx<T>) == 8;
     FFT_UNROLL
     for (int s = 0; s < n_full; s++) {
         StageHookAt<Hook> h{hook, s, total};
-        stockham_stage_rw<T, E, E, 1, 1>(x, s == 0 ? land : work, work, 0, tw, r, j, log2J, log2TPC, log2Lprev, log2P, false,
-                                         s == total - 1, h, s == 0 && swap_in);
+        if (swz && s == n_full - 1)
+            stockham_stage_rw<T, E, E, 1, 1, 2>(x, s == 0 ? land : work, work, 0, tw, r, j, log2J, log2TPC, log2Lprev, log2P,
+                                                false, s == total - 1, h, s == 0 && swap_in);
+        else
+            stockham_stage_rw<T, E, E, 1, 1>(x, s == 0 ? land : work, work, 0, tw, r, j, log2J, log2TPC, log2Lprev, log2P, false,
+                                             s == total - 1, h, s == 0 && swap_in);
     }
     // the remaining stage is always the last one: no exchange, no hook
     if (rem == 1) stockham_stage_rw<T, E, 2, 1, 1>(x, work, work, 0, tw, r, j, log2J, log2TPC, log2Lprev, log2P, false, true, StageNoHook());
-    if (rem == 2) stockham_stage_rw<T, E, 4, 1, 1>(x, work, work, 0, tw, r, j, log2J, log2TPC, log2Lprev, log2P, false, true, StageNoHook());
+    if (rem == 2) {
+        if (swz) stockham_stage_rw<T, E, 4, 1, 1, 1>(x, work, work, 0, tw, r, j, log2J, log2TPC, log2Lprev, log2P, false, true, StageNoHook());
+        else stockham_stage_rw<T, E, 4, 1, 1>(x, work, work, 0, tw, r, j, log2J, log2TPC, log2Lprev, log2P, false, true, StageNoHook());
+    }
     if (E > 8 && rem == 3)
         stockham_stage_rw<T, E, (E > 8 ? 8 : 2), 1, 1>(x, work, work, 0, tw, r, j, log2J, log2TPC, log2Lprev, log2P, false, true, StageNoHook());
 }
@@ -441,7 +451,7 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
                 }
                 // hand-over of phase ph+2: as early as its wait allows, so that the stores are long in L2 when the phase
                 // closes -- phase 0 gives the others one more stage to report their read of phase 0 (a1)
-                if (s == ((total >= 3 && ph == 0) ? 1 : 0)) {
+                if (s == ((total >= 3 && ph == 0 && !(p.tune & 1)) ? 1 : 0)) {
                     if constexpr (NK > 0) {
                         if (ph + 2 < NT) {  // hand over phase ph+2 into the window phase ph was read from
                             if (ph == 0) wait_all(g0 + 1);  // everybody has read phase 0 (phase 1: known since the wait above)

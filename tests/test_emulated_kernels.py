@@ -152,3 +152,14 @@ def test_team_kernel_three_stage_rows(dtype, threads, monkeypatch):
         y, info = E.emu_fft_team(x, d, log2ts=2, n_teams=2, threads=threads, lds_budget=65536, inplace=inplace)
         assert info[0] >= 400
         assert rel(y, oracle(x, d)) < TOL[dtype]
+
+
+def test_team_kernel_swizzled_last_stage(monkeypatch):
+    """64 x 1024 split: the row FFTs are 1024 = 16 x 16 x 4, the production stage sequence, whose last exchange goes
+    through the LDS bank swizzle (stage_swizzle in fft_kernels.h)."""
+    monkeypatch.setenv("FFT_HIP_TEAM_L1", "6")
+    x = O.gen_lcg(1 << 16, 2, 3).astype(np.complex64)
+    for d, inplace in ((-1, False), (1, True)):
+        y, info = E.emu_fft_team(x, d, log2ts=3, n_teams=2, threads=128, lds_budget=1 << 17, inplace=inplace)
+        assert info[0] >= 400
+        assert rel(y, oracle(x, d)) < TOL[np.complex64]
