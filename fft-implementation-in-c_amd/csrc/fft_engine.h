@@ -13,7 +13,7 @@
 //   template <class K> int max_blocks_per_cu(K kernel, int threads, size_t smem);
 //   void  mark(int pass_index);   // profiling hook, called after each pass launch (no-op unless enabled)
 //   void  memset_async(void*, int, size_t);
-//   bool  team_geometry(int& log2TS, int& n_teams, int& nthreads);   // false: no team kernel on this device
+//   bool  team_geometry(int& log2seats, int& n_xcc, int& nthreads);   // false: no team kernel on this device
 //   long long team_timeout_ticks();
 //   template <class K, class... A> void launch_coresident(K kernel, long long grid, int block, size_t smem, A... args);
 //
@@ -110,7 +110,8 @@ static void make_twiddle_table(std::vector<cpx<T>>& t, long long period, long lo
 template <typename T>
 struct TeamDesc {
     bool ok = false;
-    int log2L1 = 0, log2L2 = 0, log2CA = 0, log2CB = 0, log2TS = 0, n_teams = 0, NT = 0, nthreads = 0;
+    int log2L1 = 0, log2L2 = 0, log2CA = 0, log2CB = 0, log2TS = 0, NT = 0, nthreads = 0;
+    int n_xcc = 0, log2seats = 0, n_teams = 0;  // XCDs x seats per XCD; n_teams = n_xcc << (log2seats - log2TS)
     int E = 0;  // elements per thread = stage radix (fp32: 16 -> 512 threads, 8 -> 1024 threads; fp64: 8)
     int data_bytes = 0, tables_elems = 0, smem_bytes = 0;
     int o_sb1 = 0, o_sa2 = 0, o_sb2 = 0, o_t0 = 0, o_t1 = 0, sa1_bits = 0, sa2_bits = 0, t0_bits = 0;
@@ -165,27 +166,29 @@ class Pow2Plan {
 
     // ---- team kernel: geometry, tables, the L2-resident transposition windows, the control block
     void build_team(int batch) {
-        // FFT_HIP_TEAM: 0 never; 1 (default) where it measured faster than the two-pass schedule on MI355X -- fp32 with four
-        // tiles per workgroup (n = 2^20), 139 vs 126 Gpoint/s at batch 512; 2 every geometry the kernel is built for
-        // (fp32 n = 2^18..2^20, fp64 n = 2^17..2^19: those trail the two-pass schedule by 5-30 %)
+        // FFT_HIP_TEAM: 0 never; 1 (default) where it measured faster than the multi-pass schedule on MI355X
+        // (RT::team_default_on); 2 every size the kernel is built for (fft_team_list.h)
         int mode = 1;
         if (const char* e = getenv("FFT_HIP_TEAM")) mode = atoi(e);
         if (mode <= 0) return;
         TeamDesc<T> d;
-        if (!rt->team_geometry(d.log2TS, d.n_teams, d.nthreads)) return;
+        if (!rt->team_geometry(d.log2seats, d.n_xcc, d.nthreads)) return;
         const int log2V = ilog2(V);
         const int log2TE = ilog2(d.nthreads) + 3 + log2V;  // elements of a tile: threads * 8 lane accesses of V elements
-        // elements per thread: 8 * V (radix-16 stages for fp32) by default; fp32 can also run 8 per thread on twice the
-        // threads (radix-8 stages, 4 waves per SIMD) -- FFT_HIP_TEAM_E
-        d.E = 8 * V;
-        if (V == 2) {
-            static const int e_pref = getenv("FFT_HIP_TEAM_E") ? atoi(getenv("FFT_HIP_TEAM_E")) : 16;
-            if (e_pref == 8) { d.E = 8; d.nthreads *= 2; }
-        }
-        const int log2NT = log2n - d.log2TS - log2TE;
-        if (log2NT < 0 || log2NT > 2) return;  // the team's registers hold 1, 2 or 4 tiles per workgroup
+        d.E = 8 * V;  // elements per thread = the radix of the stages (16 fp32, 8 fp64)
+        // Tiles per workgroup and step (NT) x team size (TS) x tile = n.  Four tiles per workgroup keep the hand-over
+        // pipeline of fft_team.h full (two phases written during the column step, two from registers), so the team
+        // shrinks with n: TS = n / (4 tiles): 32 CUs (a whole XCD) for n = 2^20 fp32, 16, 8, 4, 2 below.  n too large
+        // for NT = 4 on a whole XCD does not fit the team's registers; NT = 2 / 1 on a whole XCD exist in the kernel
+        // (and are emulated) but lose to the multi-pass schedule.
+        int log2NT = 2;
+        if (const char* e = getenv("FFT_HIP_TEAM_TILES")) log2NT = ilog2(atoi(e));  // tests (emulation): 1 or 2 tiles
+        d.log2TS = log2n - log2NT - log2TE;
+        if (d.log2TS > d.log2seats) return;
+        if (d.log2TS < 1) return;  // a "team" of one CU exchanges nothing: single-CU sizes belong to the multi-pass plan
         d.NT = 1 << log2NT;
-        if (mode == 1 && !(SZ == 8 && d.NT == 4)) return;
+        d.n_teams = d.n_xcc << (d.log2seats - d.log2TS);
+        if (mode == 1 && !rt->team_default_on(SZ, log2n)) return;
         d.log2L1 = log2n / 2;
         if (const char* e = getenv("FFT_HIP_TEAM_L1")) d.log2L1 = atoi(e);  // experiments / tests: force the split
         d.log2L2 = log2n - d.log2L1;
@@ -194,6 +197,7 @@ class Pow2Plan {
         // a thread holds 8 * V elements of one column; fp32 pairs the lanes of adjacent rows for its 16-byte stores
         const int log2E = ilog2(d.E);
         if (d.log2L1 < log2E + log2V || d.log2L2 < log2E || d.log2CA < log2V || d.log2CB < log2V || d.log2CA > 5) return;
+        if (d.n_teams > fftk::TEAM_CTL_MAX_TEAMS) return;
         const long long L1 = 1ll << d.log2L1, L2 = 1ll << d.log2L2;
         d.data_bytes = 2 * (SZ << log2TE);  // LDS-DMA landing image + work image, one tile each
         // tables: [sa1 | sb1 | sa2 | sb2 | t0 | t1]
@@ -227,7 +231,7 @@ class Pow2Plan {
         std::copy(part.begin(), part.end(), blob.begin() + d.o_t0);
         make_twiddle_table<T>(part, n, 1ll << (log2n - d.t0_bits), 1ll << d.t0_bits);
         std::copy(part.begin(), part.end(), blob.begin() + d.o_t1);
-        d.scratch_bytes = ((size_t)SZ << (log2TE + d.log2TS)) * 2 * (size_t)d.n_teams;
+        d.scratch_bytes = ((size_t)SZ << (log2TE + d.log2TS)) * 2 * (size_t)d.n_teams;  // = 2 tiles per seat
         d.tables = (cpx<T>*)rt->dmalloc(blob.size() * SZ);
         d.scratch = (unsigned char*)rt->dmalloc(d.scratch_bytes);
         d.ctl = (unsigned*)rt->dmalloc(fftk::TEAM_CTL_WORDS * sizeof(unsigned));
@@ -237,42 +241,46 @@ class Pow2Plan {
         }
         rt->h2d(d.tables, blob.data(), blob.size() * SZ);
         // Below ~32 transforms per team the launch's fixed costs (team formation, pipeline fill, the last transforms of
-        // uneven teams) outweigh the saved HBM round trip: measured crossover with the two-pass schedule at batch ~200.
-        d.min_batch = (mode == 1 ? 32 : 1) * d.n_teams;
+        // uneven teams) outweigh the saved HBM round trip: measured crossover with the two-pass schedule at batch ~200 of 2^20
+        // (2 GiB of data per execute: 256 transforms of 2^20 fp32, 1024 of 2^18, ...)
+        d.min_batch = mode == 1 ? (int)std::max<long long>(8ll * d.n_teams, (1ll << 31) / ((long long)SZ << log2n)) : d.n_teams;
         if (const char* e = getenv("FFT_HIP_TEAM_MIN_BATCH")) d.min_batch = atoi(e);
         (void)batch;
         d.ok = true;
         team = d;
     }
 
-    template <int NT, int E>
-    void launch_team_nt_e(const fftk::TeamParams<T>& tp) {
-        const long long grid = (long long)team.n_teams << team.log2TS;
-#if defined(FFT_EMU)
-        rt->launch_coresident(fftk::team_fft_kernel<T, NT, E, 0>, grid, team.nthreads, (size_t)team.smem_bytes, tp);
-#else
-        // the device instantiations have their geometry baked in (fft_team_list.h)
-        constexpr int GEO = fftk::TeamGeo<T, NT>::value;
-        rt->launch_coresident(fftk::team_fft_kernel<T, NT, E, GEO>, grid, team.nthreads, (size_t)team.smem_bytes, tp);
-#endif
+    template <int LOG2N>
+    void launch_team_n(const fftk::TeamParams<T>& tp) {
+        const long long grid = (long long)team.n_xcc << team.log2seats;
+        constexpr int GEO = fftk::TeamGeo<T, LOG2N>::value;
+        if (GEO != 0)
+            rt->launch_coresident(fftk::team_fft_kernel<T, 4, 8 * V, (GEO ? GEO : 1)>, grid, team.nthreads, (size_t)team.smem_bytes, tp);
     }
 
     template <int NT>
-    void launch_team_nt(const fftk::TeamParams<T>& tp) {
-        if (V == 2 && team.E == 8) launch_team_nt_e<NT, (V == 2 ? 8 : 8 * V)>(tp);
-        else launch_team_nt_e<NT, 8 * V>(tp);
+    void launch_team_emu(const fftk::TeamParams<T>& tp) {
+        const long long grid = (long long)team.n_xcc << team.log2seats;
+        rt->launch_coresident(fftk::team_fft_kernel<T, NT, 8 * V, 0>, grid, team.nthreads, (size_t)team.smem_bytes, tp);
+    }
+
+    int built_geo() const {
+        switch (log2n) {
+            case 15: return fftk::TeamGeo<T, 15>::value;
+            case 16: return fftk::TeamGeo<T, 16>::value;
+            case 17: return fftk::TeamGeo<T, 17>::value;
+            case 18: return fftk::TeamGeo<T, 18>::value;
+            case 19: return fftk::TeamGeo<T, 19>::value;
+            case 20: return fftk::TeamGeo<T, 20>::value;
+            default: return 0;
+        }
     }
 
     bool team_geometry_is_built() const {
 #if defined(FFT_EMU)
         return true;
 #else
-        const int geo = FFT_TEAM_GEO(team.log2L1, team.log2L2, team.log2CA, team.log2CB, team.log2TS);
-        switch (team.NT) {
-            case 1: return fftk::TeamGeo<T, 1>::value == geo;
-            case 2: return fftk::TeamGeo<T, 2>::value == geo;
-            default: return fftk::TeamGeo<T, 4>::value == geo;
-        }
+        return team.NT == 4 && built_geo() == FFT_TEAM_GEO(team.log2L1, team.log2L2, team.log2CA, team.log2CB, team.log2TS);
 #endif
     }
 
@@ -286,7 +294,8 @@ class Pow2Plan {
         tp.tables_bytes = team.tables_elems * SZ;
         tp.data_bytes = team.data_bytes;
         tp.log2L1 = team.log2L1; tp.log2L2 = team.log2L2; tp.log2CA = team.log2CA; tp.log2CB = team.log2CB; tp.log2TS = team.log2TS;
-        tp.n_teams = team.n_teams;
+        tp.n_xcc = team.n_xcc;
+        tp.log2seats = team.log2seats;
         tp.nb = nb;
         tp.inverse = inverse ? 1 : 0;
         tp.o_sb1 = team.o_sb1; tp.o_sa2 = team.o_sa2; tp.o_sb2 = team.o_sb2; tp.o_t0 = team.o_t0; tp.o_t1 = team.o_t1;
@@ -309,11 +318,22 @@ class Pow2Plan {
         tp.trace_events = team.trace_events;
         tp.scale = scale;
         rt->memset_async(team.ctl, 0, fftk::TEAM_CTL_WORDS * sizeof(unsigned));
+#if defined(FFT_EMU)
         switch (team.NT) {
-            case 1: launch_team_nt<1>(tp); break;
-            case 2: launch_team_nt<2>(tp); break;
-            default: launch_team_nt<4>(tp); break;
+            case 1: launch_team_emu<1>(tp); break;
+            case 2: launch_team_emu<2>(tp); break;
+            default: launch_team_emu<4>(tp); break;
         }
+#else
+        switch (log2n) {  // the device instantiations have their geometry baked in (fft_team_list.h)
+            case 15: launch_team_n<15>(tp); break;
+            case 16: launch_team_n<16>(tp); break;
+            case 17: launch_team_n<17>(tp); break;
+            case 18: launch_team_n<18>(tp); break;
+            case 19: launch_team_n<19>(tp); break;
+            default: launch_team_n<20>(tp); break;
+        }
+#endif
     }
 
     // ---- twiddle-table layout of a pass: fills the bit splits and element offsets, returns the element count

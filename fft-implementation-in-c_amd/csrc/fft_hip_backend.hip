@@ -101,12 +101,17 @@ struct HipRT {
     void memset_async(void* p, int v, size_t bytes) { (void)hipMemsetAsync(p, v, bytes, stream); }
     // Team kernel (fft_team.h): built for the MI355X shape, 8 XCDs x 32 CUs, one 512-thread workgroup per CU.  The
     // kernel verifies the placement itself (HW_REG_XCC_ID); this only says whether the shape can exist here.
-    bool team_geometry(int& log2TS, int& n_teams, int& nthreads) {
+    bool team_geometry(int& log2seats, int& n_xcc, int& nthreads) {
         if (cus != 256) return false;
-        log2TS = 5;
-        n_teams = 8;
+        log2seats = 5;
+        n_xcc = 8;
         nthreads = 512;
         return true;
+    }
+    // sizes where the team kernel measured faster than the multi-pass schedule: fp32 2^17..2^20
+    // (+8, +17, +13, +10 %), fp64 2^15..2^17 (+5, +2, +7 %); fp32 2^16 (-4 %) and fp64 2^18 / 2^19 (-3 / -8 %) stay multi-pass
+    bool team_default_on(int elem_bytes, int log2n) {
+        return elem_bytes == 8 ? (log2n >= 17 && log2n <= 20) : (log2n >= 15 && log2n <= 17);
     }
     long long team_timeout_ticks() { return 20000000ll; }  // 0.2 s of the 100 MHz wall clock
     template <class K, class... A>

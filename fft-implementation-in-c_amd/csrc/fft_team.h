@@ -5,8 +5,9 @@
 // them back.  That caps the algorithmic bandwidth at half of what the memory
 // system moves.  This kernel keeps the intermediate ON the XCD:
 //
-//   * A "team" is the TS workgroups (one per CU, TS = 32 on MI355X) that run on
-//     ONE XCD and therefore share one 4 MiB L2.  Teams are formed at run time
+//   * A "team" is TS workgroups (one per CU; TS = 32, a whole XCD, for n = 2^20
+//     fp32, and 16, 8, 4, 2 of an XCD's 32 for n = 2^19 .. 2^16) that run on ONE
+//     XCD and therefore share one 4 MiB L2.  Teams are formed at run time
 //     from HW_REG_XCC_ID -- never from blockIdx -- so the placement is verified,
 //     not assumed; if the launch does not yield n_teams full teams the kernel
 //     writes a status word and exits, and the two-pass plan queued behind it (it
@@ -45,8 +46,9 @@ enum {
     TEAM_CTL_REGISTERED = 0,          // workgroups that have registered
     TEAM_CTL_STATUS = 1,              // 0 = done by this kernel; 1 = teams could not be formed (nothing touched); 2 = barrier timeout
     TEAM_CTL_COUNT = 32,              // + 32 * xcc : workgroups registered on that XCD (own 128-byte line each)
-    TEAM_CTL_FLAGS = 32 + 32 * 16,    // + 32 * xcc : the team's barrier line, one generation word per member
-    TEAM_CTL_WORDS = 32 + 32 * 16 + 32 * 16
+    TEAM_CTL_FLAGS = 32 + 32 * 16,    // + 32 * team : the team's barrier line, one generation word per member
+    TEAM_CTL_MAX_TEAMS = 256,         // 8 XCDs x 32 seats, teams of one
+    TEAM_CTL_WORDS = 32 + 32 * 16 + 32 * TEAM_CTL_MAX_TEAMS
 };
 enum { TEAM_STATUS_OK = 0, TEAM_STATUS_NO_TEAMS = 1, TEAM_STATUS_TIMEOUT = 2 };
 
@@ -55,12 +57,13 @@ struct TeamParams {
     const cpx<T>* in;
     cpx<T>* out;
     const cpx<T>* tables;    // blob [sa1 | sb1 | sa2 | sb2 | t0 | t1]
-    unsigned char* scratch;  // n_teams windows of 2 * (tile_bytes << log2TS) bytes
+    unsigned char* scratch;  // one window pair of 2 * (tile_bytes << log2TS) bytes per team
     unsigned* ctl;
     int tables_bytes;
     int data_bytes;          // LDS bytes of the data region (stage exchange / row staging image); tables follow
     int log2L1, log2L2, log2CA, log2CB, log2TS;
-    int n_teams;
+    int n_xcc;                // XCDs the launch must cover, with exactly 2^log2seats workgroups each
+    int log2seats;            // an XCD's seats are dealt to 2^(log2seats - log2TS) teams of 2^log2TS
     int nb;
     int inverse;
     int o_sb1, o_sa2, o_sb2, o_t0, o_t1;
@@ -235,7 +238,7 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
 
     // ---- team formation: who shares my L2?
     if (tid_invariant == 0) {
-        const unsigned xcc = FFT_XCC_ID(p.n_teams);
+        const unsigned xcc = FFT_XCC_ID(p.n_xcc);
         const unsigned slot = FFT_ATOMIC_ADD_AGENT(&p.ctl[TEAM_CTL_COUNT + 32 * xcc], 1u);
         FFT_ATOMIC_ADD_AGENT(&p.ctl[TEAM_CTL_REGISTERED], 1u);
         unsigned ok = 1;
@@ -250,7 +253,7 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
         if (ok) {
             for (int x = 0; x < 16; x++) {
                 const unsigned cnt = FFT_ATOMIC_LOAD_AGENT(&p.ctl[TEAM_CTL_COUNT + 32 * x]);
-                if (cnt != (x < p.n_teams ? (unsigned)TS : 0u)) ok = 0;
+                if (cnt != (x < p.n_xcc ? (1u << p.log2seats) : 0u)) ok = 0;
             }
         }
         if (p.force_no_teams) ok = 0;
@@ -262,8 +265,11 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
     }
     FFT_SYNC();
     if (!sh[2]) return;
-    const int c = (int)((FFT_UNIFORM(sh[0]) + (unsigned)p.seat_rot) & (unsigned)(TS - 1));  // my seat in the team
-    const int team = (int)FFT_UNIFORM(sh[1]);
+    // seats of an XCD in registration order; consecutive runs of TS seats form the teams of that XCD
+    const unsigned seat = (FFT_UNIFORM(sh[0]) + (unsigned)p.seat_rot) & ((1u << p.log2seats) - 1u);
+    const int c = (int)(seat & (unsigned)(TS - 1));  // my seat in the team
+    const int team = (int)((FFT_UNIFORM(sh[1]) << (p.log2seats - log2TS)) + (seat >> log2TS));
+    const int n_teams = p.n_xcc << (p.log2seats - log2TS);
 
     unsigned char* const sbase = p.scratch + (size_t)team * 2 * phase_bytes;
     unsigned* const flags = p.ctl + TEAM_CTL_FLAGS + 32 * team;
@@ -356,7 +362,7 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
 
     bool have_first = false;
     unsigned g0 = 1;  // generation of this transform's a0
-    for (int b = team; b < p.nb; b += p.n_teams, g0 += NARR) {
+    for (int b = team; b < p.nb; b += n_teams, g0 += NARR) {
         const cpx<T>* inb = p.in + (long long)b * n;
         cpx<T>* outb = p.out + (long long)b * n;
         if (!have_first) dma_column_tile(inb, 0, 0, NCH);
@@ -439,14 +445,14 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
             const int jA = tid & ((1 << log2CA) - 1), rA = tid >> log2CA;
             const int jB = tid & ((1 << log2CB) - 1), rB = tid >> log2CB;
             cpx<T> x[1][E][1];
-            const bool next_transform = (ph == NT - 1) && (b + p.n_teams < p.nb);
+            const bool next_transform = (ph == NT - 1) && (b + n_teams < p.nb);
             auto traffic = [&](int s, int total) __attribute__((always_inline)) {
                 if (s == 0) {  // the landing image is free
                     if (ph + 1 < NT) {
                         if (ph >= 1) wait_all(g0 + ph + 1);  // everybody's hand-over of phase ph+1 (a0 covers phase 1)
                         dma_row_tile(sbase + (size_t)((ph + 1) & 1) * phase_bytes);
                     } else if (next_transform) {
-                        dma_column_tile(inb + (long long)p.n_teams * n, 0, 0, NCH);
+                        dma_column_tile(inb + (long long)n_teams * n, 0, 0, NCH);
                     }
                 }
                 // hand-over of phase ph+2: as early as its wait allows, so that the stores are long in L2 when the phase

@@ -24,16 +24,17 @@ struct Runtime {
     int num_cus() { return cus; }
     void mark(int) {}
     void memset_async(void* p, int v, size_t bytes) { memset(p, v, bytes); }
-    // team kernel geometry for the emulation (0 = no team kernel): bits 0-3 log2TS + 1, 4-7 teams, 8-19 threads,
-    // bit 20: pretend the placement is wrong (one "XCD" gets a workgroup too many) to exercise the fallback
+    // team kernel geometry for the emulation (0 = no team kernel): bits 0-3 log2(seats per "XCD") + 1, 4-7 "XCDs",
+    // 8-19 threads, bit 20: pretend the placement is wrong (one "XCD" gets a workgroup too many) to exercise the fallback
     int team_mode = 0;
-    bool team_geometry(int& log2TS, int& n_teams, int& nthreads) {
+    bool team_geometry(int& log2seats, int& n_xcc, int& nthreads) {
         if (!team_mode) return false;
-        log2TS = (team_mode & 15) - 1;
-        n_teams = (team_mode >> 4) & 15;
+        log2seats = (team_mode & 15) - 1;
+        n_xcc = (team_mode >> 4) & 15;
         nthreads = (team_mode >> 8) & 4095;
         return true;
     }
+    bool team_default_on(int, int) { return true; }
     long long team_timeout_ticks() { return 60ll * 100000000ll; }
     int team_grid_skew() { return (team_mode >> 20) & 1; }
     template <class K>

@@ -23,8 +23,8 @@ def _needs_build(so):
 def lib():
     global _lib
     if _lib is None:
-        so = os.path.join(EMU_DIR, "libfft_emu.so")
-        if _needs_build(so):
+        so = os.environ.get("FFT_EMU_SO", os.path.join(EMU_DIR, "libfft_emu.so"))  # FFT_EMU_SO: a sanitizer build
+        if "FFT_EMU_SO" not in os.environ and _needs_build(so):
             subprocess.run(["g++", "-O1", "-std=c++17", "-DFFT_EMU", "-fPIC", "-shared", "-pthread", "-I" + CSRC,
                             os.path.join(EMU_DIR, "emu_fft.cpp"), "-o", so], check=True)
         _lib = C.CDLL(so)
@@ -55,16 +55,19 @@ def emu_fft(x, direction=-1, algo=0, lds_budget=0, inplace=False):
     return out, list(info)
 
 
-def emu_fft_team(x, direction=-1, log2ts=2, n_teams=2, threads=16, lds_budget=0, inplace=False, skew=False):
-    """The team kernel (fft_team.h) with a small geometry: n_teams "XCDs" of 2^log2ts workgroups of `threads`
-    threads, all running concurrently.  info[0] = 100*NT + passes when the team kernel was planned.
-    skew=True makes workgroup 0 report the wrong XCD: the kernel must give up and the two-pass fallback run."""
-    os.environ["FFT_HIP_TEAM"] = "2"  # every geometry, any batch (the default only plans it where it measured faster)
+def emu_fft_team(x, direction=-1, log2seats=2, n_xcc=2, threads=16, lds_budget=0, inplace=False, skew=False, tiles=4):
+    """The team kernel (fft_team.h) with a small geometry: n_xcc "XCDs" of 2^log2seats workgroups of `threads` threads,
+    all running concurrently.  The planner cuts each "XCD" into teams of n / (tiles * tile elements) workgroups
+    (tiles = 4 as on the device; 1 or 2 force the few-tiles variants of the kernel).  info[0] = 100*tiles + passes
+    when the team kernel was planned.  skew=True makes workgroup 0 report the wrong XCD: the kernel must give up and
+    the two-pass fallback run."""
+    os.environ["FFT_HIP_TEAM"] = "2"  # every size, any batch (the default only plans it where it measured faster)
+    os.environ["FFT_HIP_TEAM_TILES"] = str(tiles)
     x = np.ascontiguousarray(x)
     prec = 1 if x.dtype == np.complex64 else 0
     batch, n = x.shape
     info = (C.c_int * 8)()
-    mode = (log2ts + 1) | (n_teams << 4) | (threads << 8) | ((1 << 20) if skew else 0)
+    mode = (log2seats + 1) | (n_xcc << 4) | (threads << 8) | ((1 << 20) if skew else 0)
     if inplace:
         out = x.copy()
         rc = lib().emu_fft_team(out.ctypes.data, out.ctypes.data, n, batch, direction, prec, lds_budget, mode, info)

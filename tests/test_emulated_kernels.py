@@ -114,21 +114,25 @@ def test_bit_reversal_kernel_emulated(golden):
 # a data race => wrong spectrum).  Geometries are scaled down: teams of 4 or 8 workgroups of 8..128 threads.
 # ---------------------------------------------------------------------------
 TEAM_CASES = [
-    # n, batch, dtype, log2ts, n_teams, threads, lds_budget   -> tiles per workgroup (NT), radix-16/8 stage count
-    (4096, 5, np.complex64, 2, 2, 16, 16384),    # NT 4 (two phases wait in registers), 64 x 64
-    (2048, 4, np.complex64, 2, 2, 16, 8192),     # NT 2, 32 x 64
-    (1024, 7, np.complex64, 3, 2, 8, 4096),      # NT 1, 32 x 32, teams of 8
-    (2048, 5, np.complex128, 2, 3, 16, 16384),   # fp64, three teams, ragged batch
+    # n, batch, dtype, log2seats, n_xcc, threads, lds_budget, tiles -> team size
+    (4096, 5, np.complex64, 2, 2, 16, 16384, 4),    # 64 x 64, the whole "XCD" is one team of 4 (two phases wait in registers)
+    (2048, 9, np.complex64, 2, 2, 16, 8192, 4),     # 32 x 64, TWO teams of 2 per "XCD" (sub-XCD teams: n = 2^16..2^19 on the device)
+    (1024, 11, np.complex64, 3, 2, 8, 4096, 4),     # 32 x 32, four teams of 2 per "XCD", ragged batch over 8 teams
+    (2048, 4, np.complex64, 2, 2, 16, 8192, 2),     # two tiles per workgroup: both phases handed over during the column step
+    (1024, 7, np.complex64, 3, 2, 8, 4096, 1),      # one tile, one phase, teams of 8
+    (2048, 5, np.complex128, 2, 3, 16, 16384, 4),   # fp64, three "XCDs"
+    (1024, 5, np.complex128, 2, 2, 16, 8192, 4),    # fp64, teams of 2
 ]
 
 
-@pytest.mark.parametrize("n,batch,dtype,log2ts,n_teams,threads,lds", TEAM_CASES)
-def test_team_kernel(n, batch, dtype, log2ts, n_teams, threads, lds):
+@pytest.mark.parametrize("n,batch,dtype,log2seats,n_xcc,threads,lds,tiles", TEAM_CASES)
+def test_team_kernel(n, batch, dtype, log2seats, n_xcc, threads, lds, tiles):
     x = O.gen_lcg(n, 1, batch).astype(dtype)
     for d in (-1, 1):
         for inplace in (False, True):
-            y, info = E.emu_fft_team(x, d, log2ts=log2ts, n_teams=n_teams, threads=threads, lds_budget=lds, inplace=inplace)
-            assert info[0] >= 100, "team kernel was not planned"
+            y, info = E.emu_fft_team(x, d, log2seats=log2seats, n_xcc=n_xcc, threads=threads, lds_budget=lds,
+                                     inplace=inplace, tiles=tiles)
+            assert info[0] // 100 == tiles, "team kernel was not planned"
             assert rel(y, oracle(x, d)) < TOL[dtype], (n, d, inplace)
 
 
@@ -137,7 +141,7 @@ def test_team_kernel_fallback_when_teams_cannot_form():
     anything and the two-pass schedule queued behind it must produce the result (also in place)."""
     x = O.gen_lcg(4096, 2, 3).astype(np.complex64)
     for inplace in (False, True):
-        y, info = E.emu_fft_team(x, -1, log2ts=2, n_teams=2, threads=16, lds_budget=16384, inplace=inplace, skew=True)
+        y, info = E.emu_fft_team(x, -1, log2seats=2, n_xcc=2, threads=16, lds_budget=16384, inplace=inplace, skew=True)
         assert info[0] >= 100
         assert rel(y, oracle(x, -1)) < TOL[np.complex64]
 
@@ -149,7 +153,7 @@ def test_team_kernel_three_stage_rows(dtype, threads, monkeypatch):
     monkeypatch.setenv("FFT_HIP_TEAM_L1", "5")
     x = O.gen_lcg(1 << 14, 4, 5).astype(dtype)
     for d, inplace in ((-1, False), (1, True)):
-        y, info = E.emu_fft_team(x, d, log2ts=2, n_teams=2, threads=threads, lds_budget=65536, inplace=inplace)
+        y, info = E.emu_fft_team(x, d, log2seats=2, n_xcc=2, threads=threads, lds_budget=65536, inplace=inplace)
         assert info[0] >= 400
         assert rel(y, oracle(x, d)) < TOL[dtype]
 
@@ -160,6 +164,6 @@ def test_team_kernel_swizzled_last_stage(monkeypatch):
     monkeypatch.setenv("FFT_HIP_TEAM_L1", "6")
     x = O.gen_lcg(1 << 16, 2, 3).astype(np.complex64)
     for d, inplace in ((-1, False), (1, True)):
-        y, info = E.emu_fft_team(x, d, log2ts=3, n_teams=2, threads=128, lds_budget=1 << 17, inplace=inplace)
+        y, info = E.emu_fft_team(x, d, log2seats=3, n_xcc=2, threads=128, lds_budget=1 << 17, inplace=inplace)
         assert info[0] >= 400
         assert rel(y, oracle(x, d)) < TOL[np.complex64]

@@ -460,9 +460,9 @@ def test_full_size_config4_shard_and_config5(gpu_lib):
 
 
 # ---------------------------------------------------------------------------
-# team kernel (csrc/fft_team.h): a whole transform per XCD, one HBM round trip.  FFT_HIP_TEAM=2 plans it for every
-# geometry it is built for and any batch (the default policy only uses it where it measured faster: fp32 n = 2^20,
-# batch >= 256), so that all six instantiations are parity-checked on the device.
+# team kernel (csrc/fft_team.h): a whole transform per team of CUs of one XCD, one HBM round trip.  FFT_HIP_TEAM=2
+# plans it for every size it is built for and any batch (the default policy only uses it where it measured faster and
+# from 2 GiB per execute up), so that all ten instantiations are parity-checked on the device.
 # ---------------------------------------------------------------------------
 def _team_plan(monkeypatch, n, batch, direction, dtype, mode="2"):
     import fftlib
@@ -471,11 +471,16 @@ def _team_plan(monkeypatch, n, batch, direction, dtype, mode="2"):
     return plan
 
 
-@pytest.mark.parametrize("log2n,dtype,tiles", [(20, np.complex64, 4), (19, np.complex64, 2), (18, np.complex64, 1),
-                                               (19, np.complex128, 4), (18, np.complex128, 2), (17, np.complex128, 1)])
-def test_team_kernel_vs_oracle(gpu_lib, monkeypatch, log2n, dtype, tiles):
+@pytest.mark.parametrize("log2n,dtype", [(20, np.complex64), (19, np.complex64), (18, np.complex64), (17, np.complex64),
+                                         (16, np.complex64), (19, np.complex128), (18, np.complex128),
+                                         (17, np.complex128), (16, np.complex128), (15, np.complex128)])
+def test_team_kernel_vs_oracle(gpu_lib, monkeypatch, log2n, dtype):
+    """All ten device instantiations: teams of 32 (a whole XCD), 16, 8, 4 and 2 CUs."""
     import fftlib
-    n, batch = 1 << log2n, 19  # ragged: 19 transforms over 8 teams
+    tiles = 4
+    n = 1 << log2n
+    n_teams = 8 << (20 - log2n - (1 if dtype == np.complex128 else 0))
+    batch = 2 * n_teams + 3  # ragged over the teams
     x = lcg(n, batch, dtype, seed=log2n)
     buf = fftlib.DeviceBuffer(x.nbytes)
     out = fftlib.DeviceBuffer(x.nbytes)
@@ -487,7 +492,7 @@ def test_team_kernel_vs_oracle(gpu_lib, monkeypatch, log2n, dtype, tiles):
         plan.execute_ptr(buf.ptr, out.ptr)
         assert plan.team_status() == 0, "the team kernel must have done the work (teams formed, no timeout)"
         y = out.download(x.shape, dtype)
-        for b in (0, 7, 8, batch - 1):
+        for b in (0, n_teams - 1, n_teams, batch - 1):
             ref = O.oracle_fft(x[b:b + 1].astype(np.complex128), d, "dit")
             r = rel(y[b:b + 1], ref)
             assert r <= TOL[np.dtype(dtype)] and r <= TIGHT[np.dtype(dtype)], (log2n, d, b, r)
