@@ -576,3 +576,31 @@ def test_team_kernel_fallback_on_device(gpu_lib, monkeypatch):
         assert rel(buf.download(x.shape, np.complex64)[:2], ref) <= TIGHT[np.dtype(np.complex64)]
     plan.destroy()
     buf.free()
+
+
+def test_team_kernel_repeatable_bit_for_bit(gpu_lib, monkeypatch):
+    """The hand-over between the workgroups of a team relies on same-XCD visibility through the shared L2 (plain
+    stores, L1-bypassing loads, generation flags).  A stale or torn read anywhere would change some output word:
+    24 back-to-back executes of two team geometries must reproduce the first result bit for bit (tools/team_stress.py
+    is the long version: 300 executes of up to 4 GiB each)."""
+    import fftlib
+    monkeypatch.setenv("FFT_HIP_TEAM", "2")
+    for log2n, batch in ((20, 96), (18, 259)):
+        n = 1 << log2n
+        x = lcg(n, batch, np.complex64, seed=batch)
+        buf = fftlib.DeviceBuffer(x.nbytes)
+        out = fftlib.DeviceBuffer(x.nbytes)
+        buf.upload(x)
+        plan = fftlib.Plan(n, batch, -1, np.complex64)
+        assert plan.info().team_tiles == 4
+        plan.execute_ptr(buf.ptr, out.ptr)
+        assert plan.team_status() == 0
+        first = out.download(x.shape, np.complex64)
+        for it in range(6):
+            for _ in range(4):
+                plan.execute_ptr(buf.ptr, out.ptr)
+            assert plan.team_status() == 0
+            assert np.array_equal(out.download(x.shape, np.complex64).view(np.uint8), first.view(np.uint8)), (log2n, it)
+        plan.destroy()
+        buf.free()
+        out.free()
