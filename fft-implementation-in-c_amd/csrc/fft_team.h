@@ -110,8 +110,9 @@ FFT_DEVICE bool team_all_arrived(unsigned* flags, int TS, unsigned gen, int lane
 // stage layout): radix-E stages (E = the thread's element count: 16 fp32, 8 fp64) plus one stage of the remaining
 // power of two.  The first stage reads `land` and writes the work image `work`, the others run in `work`.
 // `hook(s, total)` runs in the middle of stage s < total - 1, right after the barrier that says every wave has
-// read that stage's inputs: at s == 0 the landing image is free again.  This is where the kernel issues its memory
-// traffic, so that it flies under the remaining stages.
+// read that stage's inputs (at s == 0 the landing image is free again), and once more, s == total - 1, after the
+// last stage.  These slots are where the kernel issues its memory traffic, spread out so that a CU's short memory
+// queue never makes the issuing waves wait long, and so that it flies under the remaining stages.
 template <class Hook>
 struct StageHookAt {
     Hook& hook;
@@ -147,6 +148,7 @@ FFT_DEVICE void team_all_stages(cpx<T> (&x)[1][E][1], const unsigned char* land,
     }
     if (E > 8 && rem == 3)
         stockham_stage_rw<T, E, (E > 8 ? 8 : 2), 1, 1>(x, work, work, 0, tw, r, j, log2J, log2TPC, log2Lprev, log2P, false, true, StageNoHook());
+    hook(total - 1, total);  // the last slot: after the final stage (which has no exchange, hence no mid-stage barrier)
 }
 
 // Two lanes (l, l ^ mask) hold the same slots of two ADJACENT rows (even lane: row i, odd lane: row i + 1).  For the
@@ -382,12 +384,8 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
                 team_all_stages<T, E>(x, land, work, twA, rA, jA, log2CA, log2TPCA, log2L1, [&](int s, int total) {
                     // the next tile flies during the remaining stages; issued in two halves (a CU's memory queue is short)
                     if (more) {
-                        if (total >= 3) {
-                            if (s == 0) dma_column_tile(inb, t + 1, 0, p.dma_split);
-                            if (s == 1) dma_column_tile(inb, t + 1, p.dma_split, NCH);
-                        } else if (s == 0) {
-                            dma_column_tile(inb, t + 1, 0, NCH);
-                        }
+                        if (s == 0) dma_column_tile(inb, t + 1, 0, total >= 2 ? p.dma_split : NCH);
+                        if (s == 1) dma_column_tile(inb, t + 1, p.dma_split, NCH);
                     }
                 }, p.inverse != 0);  // inverse = forward transform between two re<->im swaps: first one here
             } else if (more) {
@@ -457,7 +455,7 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
                 }
                 // hand-over of phase ph+2: as early as its wait allows, so that the stores are long in L2 when the phase
                 // closes -- phase 0 gives the others one more stage to report their read of phase 0 (a1)
-                if (s == ((total >= 3 && ph == 0 && !(p.tune & 1)) ? 1 : 0)) {
+                if (s == ((total >= 2 && ph == 0 && !(p.tune & 1)) ? 1 : 0)) {
                     if constexpr (NK > 0) {
                         if (ph + 2 < NT) {  // hand over phase ph+2 into the window phase ph was read from
                             if (ph == 0) wait_all(g0 + 1);  // everybody has read phase 0 (phase 1: known since the wait above)
@@ -481,7 +479,8 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
                 team_all_stages<T, E>(x, land, work, twB, rB, jB, log2CB, log2TPCB, log2L2, traffic, false);
             } else {
                 FFT_SYNC_LDS();
-                traffic(0, 1);
+                traffic(0, 2);
+                traffic(1, 2);
             }
             if (next_transform) have_first = true;
             ev();  // B: rows transformed
