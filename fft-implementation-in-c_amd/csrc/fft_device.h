@@ -66,7 +66,6 @@ inline T shfl_xor_any(T v, int mask) {
 #define FFT_SLEEP() sched_yield()
 #define FFT_CLOCK() emu::clock_ticks()
 #define FFT_UNIFORM(v) (v)
-#define FFT_GLDS16(gsrc, ldst, aux) memcpy((ldst), (gsrc), 16)
 #define FFT_LDS_ADDR(ptr) 0u
 #define FFT_DMA16(gsrc, lds_base_ptr, lds_base_addr, off) memcpy((lds_base_ptr) + (off), (gsrc), 16)
 #define FFT_DMA16_L2(gsrc, lds_base_ptr, lds_base_addr, off) memcpy((lds_base_ptr) + (off), (gsrc), 16)
@@ -121,9 +120,10 @@ inline T shfl_xor_any(T v, int mask) {
 #define FFT_CLOCK() ((long long)wall_clock64())
 #define FFT_UNIFORM(v) __builtin_amdgcn_readfirstlane(v)
 // LDS-DMA: 16 bytes per lane from global memory straight into LDS (global_load_lds_dwordx4), no VGPR destination.
-// The 64 lanes of a wave land in 1 KiB CONTIGUOUS LDS bytes starting at the first lane's `ldst`: every call site
-// passes ldst = base + 16 * lane-linear index.  aux: 0 default, 2 nt, 16 sc1 (bypass the vector L1).  Counts in vmcnt.
-// Hand-issued LDS-DMA (inline asm): hipcc does not see it, so it neither counts it in its own s_waitcnt bookkeeping
+// The 64 lanes of a wave land in 1 KiB CONTIGUOUS LDS bytes starting at the first lane's LDS address: every call
+// site passes the image base + 16 * lane-linear index.  Counts in vmcnt.
+// Hand-issued (inline asm; the builtin also silently drops the kernel's host stub in hipcc's host pass): hipcc does
+// not see it, so it neither counts it in its own s_waitcnt bookkeeping
 // (its waits only get stricter: vmcnt is in order) nor drains it in front of LDS reads that "may alias" -- the kernel
 // waits for its DMA itself (FFT_WAIT_VM0 / FFT_WAIT_VM_LE + barrier) before anybody reads the landing image.
 //   FFT_DMA16     from HBM, default cache policy        FFT_DMA16_L2  sc1: served by the XCD's L2, never the vector L1
@@ -164,14 +164,6 @@ __device__ __forceinline__ void fft_dma16(const void* gsrc, unsigned lane_lds_ad
     (void)lane_lds_addr;
 #endif
 }
-#define FFT_GLDS16(gsrc, ldst, aux) fft_glds16<aux>((gsrc), (ldst))
-template <int AUX>
-__device__ __forceinline__ void fft_glds16(const void* gsrc, void* ldst) {
-#if defined(__HIP_DEVICE_COMPILE__)  // the host pass of hipcc must not see the builtin (it silently drops the kernel's stub)
-    __builtin_amdgcn_global_load_lds(gsrc, (__attribute__((address_space(3))) void*)ldst, 16, 0, AUX);
-#else
-    (void)gsrc;
-    (void)ldst;
 #endif
 }
 #endif
@@ -280,42 +272,6 @@ template <typename T, int V>
 struct alignas(V * sizeof(cpx<T>)) lvec {
     cpx<T> c[V];
 };
-
-// A window of global memory read with 16-byte loads that bypass the reader's vector L1 (buffer_load_dwordx4 sc1):
-// the team kernel reads what OTHER workgroups of its XCD have just stored, straight from the shared L2.
-#if defined(FFT_EMU)
-struct L2Window {
-    const unsigned char* base;
-};
-FFT_DEVICE L2Window l2_window(const unsigned char* base, unsigned /*bytes*/) {
-    L2Window w;
-    w.base = base;
-    return w;
-}
-template <typename T>
-FFT_DEVICE vec16<T> l2_load16(const L2Window& w, unsigned off) {
-    vec16<T> v;
-    memcpy(&v, w.base + off, 16);
-    return v;
-}
-#else
-struct L2Window {
-    __amdgpu_buffer_rsrc_t rs;
-};
-FFT_DEVICE L2Window l2_window(const unsigned char* base, unsigned bytes) {
-    L2Window w;
-    w.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(base), 0, (int)bytes, 0x00020000);
-    return w;
-}
-template <typename T>
-FFT_DEVICE vec16<T> l2_load16(const L2Window& w, unsigned off) {
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(w.rs, (int)off, 0, 16 /* sc1 */);
-    vec16<T> v;
-    __builtin_memcpy(&v, &raw, 16);
-    return v;
-}
-#endif
 
 FFT_DEVICE unsigned bitrev32(unsigned v, int log2n) {
     // reverse the low log2n bits (reference include/fft_common.h:59-77, all log2n)
