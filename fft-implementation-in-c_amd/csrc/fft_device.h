@@ -165,8 +165,6 @@ __device__ __forceinline__ void fft_dma16(const void* gsrc, unsigned lane_lds_ad
 #endif
 }
 #endif
-}
-#endif
 
 namespace fftk {
 
