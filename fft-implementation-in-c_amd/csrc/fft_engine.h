@@ -305,6 +305,8 @@ class Pow2Plan {
         tp.ablate = ablate;
         static const int dma_split = getenv("FFT_HIP_TEAM_DMA_SPLIT") ? atoi(getenv("FFT_HIP_TEAM_DMA_SPLIT")) : 4;
         tp.dma_split = dma_split;
+        static const int dma_split2 = getenv("FFT_HIP_TEAM_DMA_SPLIT2") ? atoi(getenv("FFT_HIP_TEAM_DMA_SPLIT2")) : 8;
+        tp.dma_split2 = dma_split2;
         static const int seat_rot = getenv("FFT_HIP_TEAM_SEAT_ROT") ? atoi(getenv("FFT_HIP_TEAM_SEAT_ROT")) : 0;
         tp.seat_rot = seat_rot;
         static const int tile_rot = getenv("FFT_HIP_TEAM_TILE_ROT") ? atoi(getenv("FFT_HIP_TEAM_TILE_ROT")) : 4;

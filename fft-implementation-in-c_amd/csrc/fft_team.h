@@ -74,7 +74,7 @@ struct TeamParams {
     int force_no_teams;       // tests: pretend the placement check failed (exercises the two-pass fallback)
     int tile_rot;             // column_block(): seats rotate by this many blocks per tile
     int seat_rot;             // experiments: seat = (registration order + seat_rot) mod TS
-    int dma_split;            // column-tile DMA: chunks [0, dma_split) go out after stage 1, the rest after stage 2
+    int dma_split, dma_split2;  // column-tile DMA: chunks [0, dma_split) go out from slot 0, [dma_split, dma_split2) from slot 1, the rest from slot 2
     int ablate;               // experiments: 1 skip the inter-pass twiddle, 2 skip the stages
     long long* trace;         // profiling: not NULL = every workgroup logs FFT_CLOCK at its first trace_events events
     int trace_events;
@@ -385,7 +385,8 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
                     // the next tile flies during the remaining stages; issued in two halves (a CU's memory queue is short)
                     if (more) {
                         if (s == 0) dma_column_tile(inb, t + 1, 0, total >= 2 ? p.dma_split : NCH);
-                        if (s == 1) dma_column_tile(inb, t + 1, p.dma_split, NCH);
+                        if (s == 1) dma_column_tile(inb, t + 1, p.dma_split, total >= 3 ? p.dma_split2 : NCH);
+                        if (s == 2) dma_column_tile(inb, t + 1, p.dma_split2, NCH);
                     }
                 }, p.inverse != 0);  // inverse = forward transform between two re<->im swaps: first one here
             } else if (more) {

@@ -604,3 +604,33 @@ def test_team_kernel_repeatable_bit_for_bit(gpu_lib, monkeypatch):
         plan.destroy()
         buf.free()
         out.free()
+
+
+def test_team_kernels_of_two_plans_on_two_streams(gpu_lib, monkeypatch):
+    """Two plans own two streams: their team kernels may be dispatched at the same time, and each needs every CU.
+    Whatever the hardware does with them (one after the other; or both partially resident, in which case the team
+    formation of both gives up after its bounded wait and the multi-pass fallbacks run), both results must be right
+    and nothing may hang."""
+    import fftlib
+    monkeypatch.setenv("FFT_HIP_TEAM", "2")
+    n, batch = 1 << 18, 64
+    xs = [lcg(n, batch, np.complex64, seed=s) for s in (21, 22)]
+    plans = [fftlib.Plan(n, batch, -1, np.complex64) for _ in xs]
+    bufs = []
+    for x in xs:
+        b = fftlib.DeviceBuffer(x.nbytes)
+        b.upload(x)
+        bufs.append(b)
+    for rep in range(3):
+        for p, b in zip(plans, bufs):  # no sync in between: the two streams run concurrently
+            p.execute_ptr(b.ptr, b.ptr)
+        for p, b, x in zip(plans, bufs, xs):
+            assert p.team_status() in (0, 1)
+            y = b.download(x.shape, np.complex64)
+            ref = O.oracle_fft(x[:2].astype(np.complex128), -1, "dit")
+            assert rel(y[:2], ref) <= TIGHT[np.dtype(np.complex64)]
+            b.upload(x)
+    for p in plans:
+        p.destroy()
+    for b in bufs:
+        b.free()
