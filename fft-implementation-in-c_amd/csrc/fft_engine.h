@@ -112,6 +112,7 @@ struct TeamDesc {
     bool ok = false;
     int log2L1 = 0, log2L2 = 0, log2CA = 0, log2CB = 0, log2TS = 0, NT = 0, nthreads = 0;
     int n_xcc = 0, log2seats = 0, n_teams = 0;  // XCDs x seats per XCD; n_teams = n_xcc << (log2seats - log2TS)
+    bool asplit = false;  // column step on half-height, double-width tiles (128-byte row segments), fft_team.h ASPLIT
     int E = 0;  // elements per thread = stage radix (fp32: 16 -> 512 threads, 8 -> 1024 threads; fp64: 8)
     int data_bytes = 0, tables_elems = 0, smem_bytes = 0;
     int o_sb1 = 0, o_sa2 = 0, o_sb2 = 0, o_t0 = 0, o_t1 = 0, sa1_bits = 0, sa2_bits = 0, t0_bits = 0;
@@ -198,15 +199,18 @@ class Pow2Plan {
         const int log2E = ilog2(d.E);
         if (d.log2L1 < log2E + log2V || d.log2L2 < log2E || d.log2CA < log2V || d.log2CB < log2V || d.log2CA > 5) return;
         if (d.n_teams > fftk::TEAM_CTL_MAX_TEAMS) return;
-        const long long L1 = 1ll << d.log2L1, L2 = 1ll << d.log2L2;
+        // ASPLIT: built for four tiles per workgroup; on the device only where it is instantiated (RT::team_asplit)
+        d.asplit = d.NT == 4 && d.log2CA + 1 <= 5 && d.log2L1 - 1 >= log2E + log2V && rt->team_asplit(SZ, log2n);
+        const long long L1 = (1ll << d.log2L1) >> (d.asplit ? 1 : 0), L2 = 1ll << d.log2L2;  // L1: the column stage table's length
         d.data_bytes = 2 * (SZ << log2TE);  // LDS-DMA landing image + work image, one tile each
         // tables: [sa1 | sb1 | sa2 | sb2 | t0 | t1]
-        d.sa1_bits = fftk::team_stage_table_bits(SZ, d.log2L1);
+        const int log2L1tab = d.log2L1 - (d.asplit ? 1 : 0);
+        d.sa1_bits = fftk::team_stage_table_bits(SZ, log2L1tab);
         d.sa2_bits = fftk::team_stage_table_bits(SZ, d.log2L2);
         d.t0_bits = (log2n + 1) / 2;
         int ne = 1 << d.sa1_bits;
-        d.o_sb1 = ne; ne += 1 << (d.log2L1 - d.sa1_bits);
-        if (d.log2L2 == d.log2L1) { d.o_sa2 = 0; d.o_sb2 = d.o_sb1; }
+        d.o_sb1 = ne; ne += 1 << (log2L1tab - d.sa1_bits);
+        if (d.log2L2 == log2L1tab) { d.o_sa2 = 0; d.o_sb2 = d.o_sb1; }
         else { d.o_sa2 = ne; ne += 1 << d.sa2_bits; d.o_sb2 = ne; ne += 1 << (d.log2L2 - d.sa2_bits); }
         d.o_t0 = ne; ne += 1 << d.t0_bits;
         d.o_t1 = ne; ne += 1 << (log2n - d.t0_bits);
@@ -218,9 +222,9 @@ class Pow2Plan {
         for (auto& z : blob) { z.re = (T)1; z.im = (T)0; }
         make_twiddle_table<T>(part, L1, 1ll << d.sa1_bits, 1);
         std::copy(part.begin(), part.end(), blob.begin());
-        make_twiddle_table<T>(part, L1, 1ll << (d.log2L1 - d.sa1_bits), 1ll << d.sa1_bits);
+        make_twiddle_table<T>(part, L1, 1ll << (log2L1tab - d.sa1_bits), 1ll << d.sa1_bits);
         std::copy(part.begin(), part.end(), blob.begin() + d.o_sb1);
-        if (d.log2L2 != d.log2L1) {
+        if (d.log2L2 != log2L1tab) {
             make_twiddle_table<T>(part, L2, 1ll << d.sa2_bits, 1);
             std::copy(part.begin(), part.end(), blob.begin() + d.o_sa2);
             make_twiddle_table<T>(part, L2, 1ll << (d.log2L2 - d.sa2_bits), 1ll << d.sa2_bits);
@@ -254,14 +258,21 @@ class Pow2Plan {
     void launch_team_n(const fftk::TeamParams<T>& tp) {
         const long long grid = (long long)team.n_xcc << team.log2seats;
         constexpr int GEO = fftk::TeamGeo<T, LOG2N>::value;
-        if (GEO != 0)
+        if (GEO == 0) return;
+        if (fftk::TeamAsplitBuilt<T, LOG2N>::value && team.asplit)
+            rt->launch_coresident(fftk::team_fft_kernel<T, 4, 8 * V, (GEO ? GEO : 1), fftk::TeamAsplitBuilt<T, LOG2N>::value>, grid,
+                                  team.nthreads, (size_t)team.smem_bytes, tp);
+        else
             rt->launch_coresident(fftk::team_fft_kernel<T, 4, 8 * V, (GEO ? GEO : 1)>, grid, team.nthreads, (size_t)team.smem_bytes, tp);
     }
 
     template <int NT>
     void launch_team_emu(const fftk::TeamParams<T>& tp) {
         const long long grid = (long long)team.n_xcc << team.log2seats;
-        rt->launch_coresident(fftk::team_fft_kernel<T, NT, 8 * V, 0>, grid, team.nthreads, (size_t)team.smem_bytes, tp);
+        if (NT == 4 && team.asplit)
+            rt->launch_coresident(fftk::team_fft_kernel<T, 4, 8 * V, 0, true>, grid, team.nthreads, (size_t)team.smem_bytes, tp);
+        else
+            rt->launch_coresident(fftk::team_fft_kernel<T, NT, 8 * V, 0>, grid, team.nthreads, (size_t)team.smem_bytes, tp);
     }
 
     int built_geo() const {

@@ -113,6 +113,13 @@ struct HipRT {
     bool team_default_on(int elem_bytes, int log2n) {
         return elem_bytes == 8 ? (log2n >= 17 && log2n <= 20) : (log2n >= 15 && log2n <= 17);
     }
+    // the column step on 128-byte row segments (fft_team.h ASPLIT), instantiated for fp32 n = 2^20 where the plain
+    // tiles have 64-byte ones.  Measured 125 vs 137 Gpoint/s (the joined halves concentrate twiddles and hand-over in
+    // every second tile): an experiment, on only with FFT_HIP_TEAM_ASPLIT=1
+    bool team_asplit(int elem_bytes, int log2n) {
+        static const int on = getenv("FFT_HIP_TEAM_ASPLIT") ? atoi(getenv("FFT_HIP_TEAM_ASPLIT")) : 0;
+        return on && elem_bytes == 8 && log2n == 20;
+    }
     long long team_timeout_ticks() { return 20000000ll; }  // 0.2 s of the 100 MHz wall clock
     template <class K, class... A>
     void launch_coresident(K kernel, long long grid, int block, size_t smem, A... args) {

@@ -169,6 +169,33 @@ FFT_DEVICE void pair_rows(cpx<T> own_s0, cpx<T> own_s1, bool odd, int mask, vec1
     out.c[1].im = odd ? own_s1.im : recv_im;
 }
 
+// Hand over K values y[] of one column n2 (rows r + TPC*k of the current phase) into the window `sb`.  Row cp*CB + i of
+// the phase goes to workgroup cp, whose window image is its row tile in the stage layout [n2][CB rows].  fp32: the lanes
+// of rows i, i+1 (r even / odd, `pair_mask` lanes apart) pair up so that every store is 16 bytes.
+template <typename T, int K>
+FFT_DEVICE void team_hand_over(unsigned char* sb, const cpx<T> (&y)[K], int n2, int r, int log2TPC, int log2CB,
+                               unsigned tile_bytes, int pair_mask) {
+    constexpr int SZ = (int)sizeof(cpx<T>);
+    if constexpr (vec16<T>::V == 2) {
+        const bool odd = (r & 1) != 0;
+        FFT_UNROLL
+        for (int q = 0; q < K / 2; q++) {
+            const int row = (r & ~1) + (((2 * q) + (odd ? 1 : 0)) << log2TPC);  // even row of the pair
+            const int cp = row >> log2CB, i = row & ((1 << log2CB) - 1);
+            vec16<T> v;
+            pair_rows<T>(y[2 * q], y[2 * q + 1], odd, pair_mask, v);
+            *reinterpret_cast<vec16<T>*>(sb + (size_t)cp * tile_bytes + (((size_t)n2 << log2CB) + i) * SZ) = v;
+        }
+    } else {
+        FFT_UNROLL
+        for (int ee = 0; ee < K; ee++) {
+            const int row = r + (ee << log2TPC);
+            const int cp = row >> log2CB, i = row & ((1 << log2CB) - 1);
+            *reinterpret_cast<cpx<T>*>(sb + (size_t)cp * tile_bytes + (((size_t)n2 << log2CB) + i) * SZ) = y[ee];
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // The kernel.  Per transform a workgroup signals NT + 1 "arrivals" on its team's flag line (generation numbers
 // count up across transforms); a wait is a poll of the whole line by every wave that needs it:
@@ -184,7 +211,14 @@ FFT_DEVICE void pair_rows(cpx<T> own_s0, cpx<T> own_s1, bool odd, int mask, vec1
 // E = elements per thread, all of ONE column = the radix of the stages.  A tile is 64 KiB (4096 * V16 elements), so the
 // workgroup has 4096 * V16 / E threads: fp32 E = 16 -> 512 threads (2 waves per SIMD), E = 8 -> 1024 threads (4 waves per
 // SIMD: one more LDS exchange per tile, twice the waves to hide LDS latency and barriers behind); fp64 E = 8 -> 512.
-template <typename T, int NT, int E, int GEO>
+//
+// ASPLIT: the column step reads 128-byte row segments instead of 64-byte ones (a CU's memory pipeline streams those
+// half again as fast).  A column tile becomes HALF as high and TWICE as wide: the even rows, then the
+// odd rows, of 2 CA columns; each half is a length-L1/2 transform, and a radix-2 butterfly in registers joins them,
+//     Y[k'] = Ye[k'] + W_L1^k' Yo[k'],   Y[k' + L1/2] = Ye[k'] - W_L1^k' Yo[k'],
+// which puts the low half of the rows (phases 0, 1: handed over at once) and the high half (phases 2, 3: kept) into
+// the same thread.  Row step, windows and arrivals are untouched.
+template <typename T, int NT, int E, int GEO, bool ASPLIT = false>
 FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E) team_fft_kernel(TeamParams<T> p) {
     constexpr int V16 = vec16<T>::V;  // complex values per 16-byte lane access of HBM / L2: 2 (fp32) or 1 (fp64)
     constexpr int log2V16 = Log2<V16>::value;
@@ -231,8 +265,8 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
     StageTw<T> twA, twB;
     twA.sa = tab;
     twA.sb = tab + p.o_sb1;
-    twA.sa_bits = team_stage_table_bits(SZ, log2L1);
-    twA.log2L = log2L1;
+    twA.sa_bits = team_stage_table_bits(SZ, ASPLIT ? log2L1 - 1 : log2L1);  // ASPLIT: the planner lays the table out for L1 / 2
+    twA.log2L = ASPLIT ? log2L1 - 1 : log2L1;
     twB.sa = tab + p.o_sa2;
     twB.sb = tab + p.o_sb2;
     twB.sa_bits = team_stage_table_bits(SZ, log2L2);
@@ -337,29 +371,29 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
         for (int i = 0; i < NCH; i++)
             FFT_DMA16_L2(src + (size_t)i * nthreads * 16, land, land_lds, (unsigned)(i * nthreads + tid) * 16u);
     };
-    // Hand over the EP values y[] (rows rA + TPCA*ee of the phase, column c0 + jA) into window `sb`.  Row cp*CB + i of
-    // the phase goes to workgroup cp, whose window image is its row tile in the stage layout [n2][CB rows].  fp32: the
-    // lanes of rows i, i+1 (rA even / odd, CA lanes apart) pair up so that every store is 16 bytes.
+    // column tile t covers columns [column_block(t) * CA, + CA); ASPLIT: half tile t = (group t / 2, row parity t % 2)
+    // covers the 2 CA columns [column_group(t / 2) * 2 CA, + 2 CA)
+    auto column_group = [&](int g) __attribute__((always_inline)) { return (g << log2TS) + ((c + p.tile_rot * g) & (TS - 1)); };
     auto hand_over = [&](unsigned char* sb, const cpx<T> (&y)[EP], int tt, int rA, int jA) __attribute__((always_inline)) {
-        const int n2 = (column_block(tt) << log2CA) + jA;
-        if constexpr (V16 == 2) {
-            const bool odd = (rA & 1) != 0;
-            FFT_UNROLL
-            for (int q = 0; q < EP / 2; q++) {
-                const int row = (rA & ~1) + (((2 * q) + (odd ? 1 : 0)) << log2TPCA);  // even row of the pair
-                const int cp = row >> log2CB, i = row & ((1 << log2CB) - 1);
-                vec16<T> v;
-                pair_rows<T>(y[2 * q], y[2 * q + 1], odd, 1 << log2CA, v);
-                *reinterpret_cast<vec16<T>*>(sb + (size_t)cp * tile_bytes + (((size_t)n2 << log2CB) + i) * SZ) = v;
-            }
-        } else {
-            FFT_UNROLL
-            for (int ee = 0; ee < EP; ee++) {
-                const int row = rA + (ee << log2TPCA);
-                const int cp = row >> log2CB, i = row & ((1 << log2CB) - 1);
-                *reinterpret_cast<cpx<T>*>(sb + (size_t)cp * tile_bytes + (((size_t)n2 << log2CB) + i) * SZ) = y[ee];
-            }
-        }
+        team_hand_over<T, EP>(sb, y, (column_block(tt) << log2CA) + jA, rA, log2TPCA, log2CB, tile_bytes, 1 << log2CA);
+    };
+    // ASPLIT geometry: thread (jA2, rA2) owns rows k' = rA2 + TPCA2 * e of column jA2 of a half tile
+    const int log2H1 = log2L1 - 1, log2CA2 = log2CA + 1, log2TPCA2 = log2H1 - log2E;
+    cpx<T> keep2[ASPLIT ? NT / 2 : 1][E];  // ASPLIT: the high half of the rows (phases 2, 3) of each column group
+    auto dma_half_tile = [&](const cpx<T>* inb, int t, int i0, int i1) __attribute__((always_inline)) {
+        int tid = tid_invariant;
+        FFT_OPAQUE(tid);
+        const int log2CPR = log2CA2 - log2V16;
+        const int c0 = column_group(t >> 1) << log2CA2;
+        const cpx<T>* src = inb + ((long long)(2 * (tid >> log2CPR) + (t & 1)) << log2L2) + c0 + V16 * (tid & ((1 << log2CPR) - 1));
+        const long long step = (long long)(2 * (nthreads >> log2CPR)) << log2L2;
+        FFT_UNROLL
+        for (int i = 0; i < NCH; i++)
+            if (i >= i0 && i < i1) FFT_DMA16(src + i * step, land, land_lds, (unsigned)(i * nthreads + tid) * 16u);
+    };
+    auto dma_first_tile = [&](const cpx<T>* inb) __attribute__((always_inline)) {
+        if constexpr (ASPLIT) dma_half_tile(inb, 0, 0, NCH);
+        else dma_column_tile(inb, 0, 0, NCH);
     };
 
     bool have_first = false;
@@ -367,9 +401,67 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
     for (int b = team; b < p.nb; b += n_teams, g0 += NARR) {
         const cpx<T>* inb = p.in + (long long)b * n;
         cpx<T>* outb = p.out + (long long)b * n;
-        if (!have_first) dma_column_tile(inb, 0, 0, NCH);
+        if (!have_first) dma_first_tile(inb);
 
         // ================= step A: L2-strided column FFTs of length L1; phases 0, 1 are handed over at once
+        if constexpr (ASPLIT) {
+            static_assert(!ASPLIT || NT == 4, "the even / odd row split is built for four tiles per workgroup");
+            cpx<T> ye[E];
+            FFT_NOUNROLL
+            for (int t = 0; t < NT; t++) {  // half tile t: column group t / 2, rows of parity t % 2
+                int tid = tid_invariant;
+                FFT_OPAQUE(tid);
+                const int jA2 = tid & ((1 << log2CA2) - 1), rA2 = tid >> log2CA2;
+                cpx<T> x[1][E][1];
+                FFT_WAIT_VM0();
+                FFT_SYNC_LDS();
+                ev();  // A: half tile landed
+                const bool more = (t + 1 < NT);
+                team_all_stages<T, E>(x, land, work, twA, rA2, jA2, log2CA2, log2TPCA2, log2H1, [&](int s, int total) {
+                    if (more) {
+                        if (s == 0) dma_half_tile(inb, t + 1, 0, total >= 2 ? p.dma_split : NCH);
+                        if (s == 1) dma_half_tile(inb, t + 1, p.dma_split, total >= 3 ? p.dma_split2 : NCH);
+                        if (s == 2) dma_half_tile(inb, t + 1, p.dma_split2, NCH);
+                    }
+                }, p.inverse != 0);
+                if ((t & 1) == 0) {
+                    FFT_UNROLL
+                    for (int e = 0; e < E; e++) ye[e] = x[0][e][0];
+                } else {
+                    // join the halves, apply W_n^(k1 n2), hand the low rows over, keep the high rows
+                    const cpx<T>* t0 = tab + p.o_t0;
+                    const cpx<T>* t1 = tab + p.o_t1;
+                    const unsigned m0 = (1u << p.t0_bits) - 1u;
+                    const unsigned n2 = (unsigned)(column_group(t >> 1) << log2CA2) + (unsigned)jA2;
+                    const unsigned mh = n2 << log2H1;  // W_n^(L1/2 * n2): what the high rows' twiddle has on top of the low rows'
+                    const cpx<T> w_half = cmul(t0[mh & m0], t1[mh >> p.t0_bits]);
+                    cpx<T> lo[E];
+                    FFT_UNROLL
+                    for (int e = 0; e < E; e++) {
+                        const unsigned kk = (unsigned)(rA2 + (e << log2TPCA2));
+                        const unsigned mj = kk << log2L2;  // W_L1^k' = W_n^(k' L2)
+                        const cpx<T> tq = cmul(x[0][e][0], cmul(t0[mj & m0], t1[mj >> p.t0_bits]));
+                        const unsigned m = kk * n2;
+                        const cpx<T> w = cmul(t0[m & m0], t1[m >> p.t0_bits]);
+                        lo[e] = cmul(cadd(ye[e], tq), w);
+                        const cpx<T> hi = cmul(csub(ye[e], tq), cmul(w, w_half));
+                        FFT_UNROLL
+                        for (int gg = 0; gg < NT / 2; gg++)
+                            if ((t >> 1) == gg) keep2[gg][e] = hi;
+                    }
+                    if (t == 1 && g0 > 1) wait_all(g0 - 1);  // the windows' last readers (previous transform) are done
+                    FFT_UNROLL
+                    for (int ph = 0; ph < 2; ph++) {
+                        cpx<T> y[E / 2];
+                        FFT_UNROLL
+                        for (int k = 0; k < E / 2; k++) y[k] = lo[ph * (E / 2) + k];
+                        team_hand_over<T, E / 2>(sbase + (size_t)ph * phase_bytes, y, (int)n2, rA2, log2TPCA2, log2CB, tile_bytes,
+                                                 1 << log2CA2);
+                    }
+                }
+                ev();  // A: half tile transformed
+            }
+        } else {
         FFT_NOUNROLL
         for (int t = 0; t < NT; t++) {
             int tid = tid_invariant;
@@ -424,6 +516,7 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
             }
             ev();  // A: tile transformed, phases 0/1 hand-over issued
         }
+        }
         FFT_WAIT_VM0();
         FFT_SYNC_LDS();
         arrive(g0);  // a0
@@ -451,7 +544,7 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
                         if (ph >= 1) wait_all(g0 + ph + 1);  // everybody's hand-over of phase ph+1 (a0 covers phase 1)
                         dma_row_tile(sbase + (size_t)((ph + 1) & 1) * phase_bytes);
                     } else if (next_transform) {
-                        dma_column_tile(inb + (long long)n_teams * n, 0, 0, NCH);
+                        dma_first_tile(inb + (long long)n_teams * n);
                     }
                 }
                 // hand-over of phase ph+2: as early as its wait allows, so that the stores are long in L2 when the phase
@@ -460,15 +553,32 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
                     if constexpr (NK > 0) {
                         if (ph + 2 < NT) {  // hand over phase ph+2 into the window phase ph was read from
                             if (ph == 0) wait_all(g0 + 1);  // everybody has read phase 0 (phase 1: known since the wait above)
-                            FFT_UNROLL
-                            for (int pp = 0; pp < NK; pp++) {
-                                if (ph == pp) {
+                            if constexpr (ASPLIT) {
+                                const int jA2 = tid & ((1 << log2CA2) - 1), rA2 = tid >> log2CA2;
+                                const bool second = (ph == 1);  // phase 3 = the upper half of the kept rows
+                                FFT_UNROLL
+                                for (int gg = 0; gg < NT / 2; gg++) {
+                                    cpx<T> y[E / 2];
                                     FFT_UNROLL
-                                    for (int tt = 0; tt < NT; tt++) {
-                                        cpx<T> y[EP];
+                                    for (int k = 0; k < E / 2; k++) {  // value by value (see pair_rows)
+                                        const cpx<T> a = keep2[gg][k], b2 = keep2[gg][E / 2 + k];
+                                        y[k] = mk<T>(second ? b2.re : a.re, second ? b2.im : a.im);
+                                    }
+                                    team_hand_over<T, E / 2>(sbase + (size_t)(ph & 1) * phase_bytes, y,
+                                                             (column_group(gg) << log2CA2) + jA2, rA2, log2TPCA2, log2CB, tile_bytes,
+                                                             1 << log2CA2);
+                                }
+                            } else {
+                                FFT_UNROLL
+                                for (int pp = 0; pp < NK; pp++) {
+                                    if (ph == pp) {
                                         FFT_UNROLL
-                                        for (int ee = 0; ee < EP; ee++) y[ee] = keep[tt][pp * EP + ee];
-                                        hand_over(sbase + (size_t)(ph & 1) * phase_bytes, y, tt, rA, jA);
+                                        for (int tt = 0; tt < NT; tt++) {
+                                            cpx<T> y[EP];
+                                            FFT_UNROLL
+                                            for (int ee = 0; ee < EP; ee++) y[ee] = keep[tt][pp * EP + ee];
+                                            hand_over(sbase + (size_t)(ph & 1) * phase_bytes, y, tt, rA, jA);
+                                        }
                                     }
                                 }
                             }

@@ -20,4 +20,10 @@ template <> struct TeamGeo<double, 18> { static constexpr int value = FFT_TEAM_G
 template <> struct TeamGeo<double, 17> { static constexpr int value = FFT_TEAM_GEO(8, 9, 4, 3, 3); };
 template <> struct TeamGeo<double, 16> { static constexpr int value = FFT_TEAM_GEO(8, 8, 4, 4, 2); };
 template <> struct TeamGeo<double, 15> { static constexpr int value = FFT_TEAM_GEO(7, 8, 5, 4, 1); };
+// sizes whose ASPLIT variant (128-byte column segments) is instantiated too
+template <typename T, int LOG2N>
+struct TeamAsplitBuilt {
+    static constexpr bool value = false;
+};
+template <> struct TeamAsplitBuilt<float, 20> { static constexpr bool value = true; };
 }  // namespace fftk

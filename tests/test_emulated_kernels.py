@@ -167,3 +167,16 @@ def test_team_kernel_swizzled_last_stage(monkeypatch):
         y, info = E.emu_fft_team(x, d, log2seats=3, n_xcc=2, threads=128, lds_budget=1 << 17, inplace=inplace)
         assert info[0] >= 400
         assert rel(y, oracle(x, d)) < TOL[np.complex64]
+
+
+@pytest.mark.parametrize("n,batch,dtype,log2seats,threads,lds", [(4096, 5, np.complex64, 2, 16, 16384), (1 << 14, 3, np.complex64, 2, 64, 65536),
+                                                                  (2048, 5, np.complex128, 2, 16, 16384)])
+def test_team_kernel_even_odd_row_split(n, batch, dtype, log2seats, threads, lds, monkeypatch):
+    """ASPLIT: the column step runs on half-height, double-width tiles (even rows, then odd rows: 128-byte row segments
+    on the device) joined by a radix-2 butterfly in registers; the row step is unchanged."""
+    monkeypatch.setenv("FFT_EMU_TEAM_ASPLIT", "1")
+    x = O.gen_lcg(n, 7, batch).astype(dtype)
+    for d, inplace in ((-1, False), (1, True)):
+        y, info = E.emu_fft_team(x, d, log2seats=log2seats, n_xcc=2, threads=threads, lds_budget=lds, inplace=inplace)
+        assert info[0] >= 400 and info[6] == 1, "the split column step was not planned"
+        assert rel(y, oracle(x, d)) < TOL[dtype]

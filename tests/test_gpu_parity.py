@@ -5,10 +5,14 @@ against the golden vectors generated from the real reference.
 
 Tolerances (BASELINE.json north_star): rel-L2 <= 1e-6 for fp64, <= 1e-4 for fp32.
 """
+import os
+
 import numpy as np
 import pytest
 
 import oracle_lib as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -634,3 +638,33 @@ def test_team_kernels_of_two_plans_on_two_streams(gpu_lib, monkeypatch):
         p.destroy()
     for b in bufs:
         b.free()
+
+
+def test_team_kernel_even_odd_row_split(gpu_lib, monkeypatch):
+    """FFT_HIP_TEAM_ASPLIT=1: the column step of n = 2^20 fp32 on half-height, double-width tiles (128-byte row
+    segments) joined by a radix-2 butterfly in registers -- an experiment (slower than the plain tiles), kept
+    parity-green."""
+    import subprocess
+    import sys
+    code = (
+        "import os, sys, numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import fftlib, oracle_lib as O\n"
+        "fftlib.init()\n"
+        "n, batch = 1 << 20, 24\n"
+        "x = O.gen_lcg(n, 31, batch).astype(np.complex64)\n"
+        "buf = fftlib.DeviceBuffer(x.nbytes); buf.upload(x)\n"
+        "for d in (-1, 1):\n"
+        "    p = fftlib.Plan(n, batch, d, np.complex64)\n"
+        "    buf.upload(x); p.execute_ptr(buf.ptr, buf.ptr)\n"
+        "    assert p.team_status() == 0\n"
+        "    y = buf.download(x.shape, np.complex64)\n"
+        "    for b in (0, 8, 23):\n"
+        "        ref = O.oracle_fft(x[b:b+1].astype(np.complex128), d, 'dit')\n"
+        "        r = float(np.linalg.norm(y[b:b+1] - ref) / np.linalg.norm(ref))\n"
+        "        assert r < 2e-6, (d, b, r)\n"
+        "print('ok')\n"
+    ) % (os.path.join(ROOT, "fft-implementation-in-c_amd"), os.path.join(ROOT, "tests"))
+    env = dict(os.environ, FFT_HIP_TEAM="2", FFT_HIP_TEAM_ASPLIT="1")  # read once per process: a fresh one
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
