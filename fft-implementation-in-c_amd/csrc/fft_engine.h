@@ -38,6 +38,7 @@
 
 #include "fft_kernels.h"
 #include "fft_team_list.h"
+#include "fft_team_defer.h"
 
 namespace ffteng {
 
@@ -112,6 +113,7 @@ struct TeamDesc {
     bool ok = false;
     int log2L1 = 0, log2L2 = 0, log2CA = 0, log2CB = 0, log2TS = 0, NT = 0, nthreads = 0;
     int n_xcc = 0, log2seats = 0, n_teams = 0;  // XCDs x seats per XCD; n_teams = n_xcc << (log2seats - log2TS)
+    bool defer = false;   // team_defer_kernel: the last row phase of a transform runs after the next one's column step
     bool asplit = false;  // column step on half-height, double-width tiles (128-byte row segments), fft_team.h ASPLIT
     int E = 0;  // elements per thread = stage radix (fp32: 16 -> 512 threads, 8 -> 1024 threads; fp64: 8)
     int data_bytes = 0, tables_elems = 0, smem_bytes = 0;
@@ -235,7 +237,8 @@ class Pow2Plan {
         std::copy(part.begin(), part.end(), blob.begin() + d.o_t0);
         make_twiddle_table<T>(part, n, 1ll << (log2n - d.t0_bits), 1ll << d.t0_bits);
         std::copy(part.begin(), part.end(), blob.begin() + d.o_t1);
-        d.scratch_bytes = ((size_t)SZ << (log2TE + d.log2TS)) * 2 * (size_t)d.n_teams;  // = 2 tiles per seat
+        d.defer = d.NT == 4 && !d.asplit && rt->team_defer(SZ, log2n);
+        d.scratch_bytes = ((size_t)SZ << (log2TE + d.log2TS)) * (d.defer ? 3 : 2) * (size_t)d.n_teams;  // 2 (3) windows of TS tiles per team
         d.tables = (cpx<T>*)rt->dmalloc(blob.size() * SZ);
         d.scratch = (unsigned char*)rt->dmalloc(d.scratch_bytes);
         d.ctl = (unsigned*)rt->dmalloc(fftk::TEAM_CTL_WORDS * sizeof(unsigned));
@@ -259,7 +262,9 @@ class Pow2Plan {
         const long long grid = (long long)team.n_xcc << team.log2seats;
         constexpr int GEO = fftk::TeamGeo<T, LOG2N>::value;
         if (GEO == 0) return;
-        if (fftk::TeamAsplitBuilt<T, LOG2N>::value && team.asplit)
+        if (team.defer)
+            rt->launch_coresident(fftk::team_defer_kernel<T, 8 * V, (GEO ? GEO : 1)>, grid, team.nthreads, (size_t)team.smem_bytes, tp);
+        else if (fftk::TeamAsplitBuilt<T, LOG2N>::value && team.asplit)
             rt->launch_coresident(fftk::team_fft_kernel<T, 4, 8 * V, (GEO ? GEO : 1), fftk::TeamAsplitBuilt<T, LOG2N>::value>, grid,
                                   team.nthreads, (size_t)team.smem_bytes, tp);
         else
@@ -269,7 +274,9 @@ class Pow2Plan {
     template <int NT>
     void launch_team_emu(const fftk::TeamParams<T>& tp) {
         const long long grid = (long long)team.n_xcc << team.log2seats;
-        if (NT == 4 && team.asplit)
+        if (NT == 4 && team.defer)
+            rt->launch_coresident(fftk::team_defer_kernel<T, 8 * V, 0>, grid, team.nthreads, (size_t)team.smem_bytes, tp);
+        else if (NT == 4 && team.asplit)
             rt->launch_coresident(fftk::team_fft_kernel<T, 4, 8 * V, 0, true>, grid, team.nthreads, (size_t)team.smem_bytes, tp);
         else
             rt->launch_coresident(fftk::team_fft_kernel<T, NT, 8 * V, 0>, grid, team.nthreads, (size_t)team.smem_bytes, tp);

@@ -120,6 +120,12 @@ struct HipRT {
         static const int on = getenv("FFT_HIP_TEAM_ASPLIT") ? atoi(getenv("FFT_HIP_TEAM_ASPLIT")) : 0;
         return on && elem_bytes == 8 && log2n == 20;
     }
+    // team_defer_kernel (fft_team_defer.h: the last row phase fills the turn of the next transform) instead of
+    // team_fft_kernel: +3..6 % at n = 2^20, 2^19 and fp64, even at 2^18, 2^17; FFT_HIP_TEAM_DEFER=0 keeps the plain kernel
+    bool team_defer(int /*elem_bytes*/, int /*log2n*/) {
+        static const int on = getenv("FFT_HIP_TEAM_DEFER") ? atoi(getenv("FFT_HIP_TEAM_DEFER")) : 1;
+        return on != 0;
+    }
     long long team_timeout_ticks() { return 20000000ll; }  // 0.2 s of the 100 MHz wall clock
     template <class K, class... A>
     void launch_coresident(K kernel, long long grid, int block, size_t smem, A... args) {

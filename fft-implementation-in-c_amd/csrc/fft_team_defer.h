@@ -1,0 +1,325 @@
+// fft_team_defer.h -- team_defer_kernel: the team kernel of fft_team.h with the LAST row phase of every transform
+// deferred until after the column step of the next one.
+//
+// In team_fft_kernel every workgroup reaches the turn from the column step (A) to the row step (B) and then has
+// nothing to do while (i) its last hand-over stores drain, (ii) the slowest member of the team arrives and (iii) the
+// first row tile makes its trip from L2 / Infinity Cache: 8 us of 60 at n = 2^20.  Here the turn is filled with
+// useful work that does not depend on it -- row phase 3 of the PREVIOUS transform:
+//
+//     A(i) t0 t1 t2 t3 | B(i-1) phase 3 | B(i) phase 0, 1, 2 | A(i+1) ... | B(i) phase 3 | ...
+//
+// The row tile of that deferred phase is fetched under the last column tile, the first row tile of transform i under
+// the deferred phase's stages.  Phase 3 is handed over into a third window (S2), because S1 is rewritten by the
+// next column step before the deferred phase reads.  Four arrivals per transform (generation 4 it + k):
+//   X1  column step done: my hand-over of phases 0, 1 is in L2, the deferred row tile (phase 3 of it-1) has landed here
+//   X2  row tile 0 has landed here (S0 may be rewritten)
+//   X3  end of phase 0: row tile 1 has landed, my hand-over of phase 2 (into S0) is in L2
+//   X4  end of phase 1: row tile 2 has landed, my hand-over of phase 3 (into S2) is in L2
+#pragma once
+
+#include "fft_team.h"
+
+namespace fftk {
+
+template <typename T, int E, int GEO>
+FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E) team_defer_kernel(TeamParams<T> p) {
+    constexpr int NT = 4;
+    constexpr int V16 = vec16<T>::V;
+    constexpr int log2V16 = Log2<V16>::value;
+    constexpr int log2E = Log2<E>::value;
+    constexpr int NCH = E / V16;
+    constexpr int SZ = (int)sizeof(cpx<T>);
+    constexpr int EP = E / NT;
+    constexpr int NK = 2;
+    constexpr int log2NT = 2;
+    FFT_DYN_SMEM(smem);
+
+    const int tid_invariant = FFT_TID;
+    const int nthreads = FFT_NTHREADS;
+    const int log2L1 = GEO ? (GEO & 31) : p.log2L1;
+    const int log2L2 = GEO ? ((GEO >> 5) & 31) : p.log2L2;
+    const int log2CA = GEO ? ((GEO >> 10) & 31) : p.log2CA;
+    const int log2CB = GEO ? ((GEO >> 15) & 31) : p.log2CB;
+    const int log2TS = GEO ? ((GEO >> 20) & 31) : p.log2TS;
+    const int TS = 1 << log2TS;
+    const int log2TPCA = log2L1 - log2E;
+    const int log2TPCB = log2L2 - log2E;
+    const long long n = 1ll << (log2L1 + log2L2);
+    const unsigned tile_bytes = (unsigned)SZ << (log2L1 + log2CA);
+    const unsigned phase_bytes = tile_bytes << log2TS;
+
+    unsigned char* const land = smem;
+    unsigned char* const work = smem + tile_bytes;
+    unsigned char* const tab_bytes = smem + 2 * tile_bytes;
+    const unsigned land_lds = FFT_LDS_ADDR(land);
+    {
+        const vec16<T>* src = reinterpret_cast<const vec16<T>*>(p.tables);
+        vec16<T>* dst = reinterpret_cast<vec16<T>*>(tab_bytes);
+        for (int i = tid_invariant; i < (p.tables_bytes >> 4); i += nthreads) dst[i] = src[i];
+    }
+    const cpx<T>* tab = reinterpret_cast<const cpx<T>*>(tab_bytes);
+    volatile unsigned* sh = reinterpret_cast<volatile unsigned*>(tab_bytes + p.tables_bytes);
+    StageTw<T> twA, twB;
+    twA.sa = tab;
+    twA.sb = tab + p.o_sb1;
+    twA.sa_bits = team_stage_table_bits(SZ, log2L1);
+    twA.log2L = log2L1;
+    twB.sa = tab + p.o_sa2;
+    twB.sb = tab + p.o_sb2;
+    twB.sa_bits = team_stage_table_bits(SZ, log2L2);
+    twB.log2L = log2L2;
+
+    // ---- team formation (as in team_fft_kernel)
+    if (tid_invariant == 0) {
+        const unsigned xcc = FFT_XCC_ID(p.n_xcc);
+        const unsigned slot = FFT_ATOMIC_ADD_AGENT(&p.ctl[TEAM_CTL_COUNT + 32 * xcc], 1u);
+        FFT_ATOMIC_ADD_AGENT(&p.ctl[TEAM_CTL_REGISTERED], 1u);
+        unsigned ok = 1;
+        const long long t0 = FFT_CLOCK();
+        while (FFT_ATOMIC_LOAD_AGENT(&p.ctl[TEAM_CTL_REGISTERED]) < (unsigned)FFT_NBLOCKS) {
+            if (FFT_ATOMIC_LOAD_AGENT(&p.ctl[TEAM_CTL_STATUS]) != 0 || FFT_CLOCK() - t0 > p.timeout_ticks) {
+                ok = 0;
+                break;
+            }
+            FFT_SLEEP();
+        }
+        if (ok) {
+            for (int x = 0; x < 16; x++) {
+                const unsigned cnt = FFT_ATOMIC_LOAD_AGENT(&p.ctl[TEAM_CTL_COUNT + 32 * x]);
+                if (cnt != (x < p.n_xcc ? (1u << p.log2seats) : 0u)) ok = 0;
+            }
+        }
+        if (p.force_no_teams) ok = 0;
+        if (!ok) FFT_ATOMIC_STORE_AGENT(&p.ctl[TEAM_CTL_STATUS], (unsigned)TEAM_STATUS_NO_TEAMS);
+        sh[0] = slot;
+        sh[1] = xcc;
+        sh[2] = ok;
+        sh[3] = 0;
+    }
+    FFT_SYNC();
+    if (!sh[2]) return;
+    const unsigned seat = (FFT_UNIFORM(sh[0]) + (unsigned)p.seat_rot) & ((1u << p.log2seats) - 1u);
+    const int c = (int)(seat & (unsigned)(TS - 1));
+    const int team = (int)((FFT_UNIFORM(sh[1]) << (p.log2seats - log2TS)) + (seat >> log2TS));
+    const int n_teams = p.n_xcc << (p.log2seats - log2TS);
+    const int M = team < p.nb ? (p.nb - team + n_teams - 1) / n_teams : 0;  // transforms of this team
+    if (M == 0) return;
+
+    unsigned char* const sbase = p.scratch + (size_t)team * 3 * phase_bytes;  // windows S0, S1, S2
+    unsigned* const flags = p.ctl + TEAM_CTL_FLAGS + 32 * team;
+
+    int n_ev = 0;
+    auto ev = [&]() __attribute__((always_inline)) {
+        if (p.trace && tid_invariant == 0 && n_ev < p.trace_events - 1) {
+            p.trace[(long long)FFT_BID * p.trace_events + n_ev] = FFT_CLOCK();
+            n_ev++;
+        }
+    };
+    ev();
+    if (p.trace && tid_invariant == 0 && p.trace_events > 1) p.trace[(long long)FFT_BID * p.trace_events + p.trace_events - 1] = (team << 8) | c;
+
+    auto wait_all = [&](int g) __attribute__((always_inline)) {
+        if (g <= 0 || sh[3]) return;
+        const long long t0 = FFT_CLOCK();
+        while (!team_all_arrived(flags, TS, (unsigned)g, tid_invariant & (FFT_TEAM_POLL_LANES - 1))) {
+            if (FFT_CLOCK() - t0 > p.timeout_ticks) {
+                FFT_ATOMIC_STORE_AGENT(&p.ctl[TEAM_CTL_STATUS], (unsigned)TEAM_STATUS_TIMEOUT);
+                sh[3] = 1;
+                break;
+            }
+            FFT_SLEEP();
+        }
+    };
+    auto arrive = [&](int g) __attribute__((always_inline)) {
+        if (tid_invariant == 0) FFT_L2_FLAG_STORE(&flags[c], (unsigned)g);
+    };
+    auto column_block = [&](int t) __attribute__((always_inline)) { return (t << log2TS) + ((c + p.tile_rot * t) & (TS - 1)); };
+    auto in_of = [&](int it) __attribute__((always_inline)) { return p.in + (long long)(team + (long long)it * n_teams) * n; };
+    auto out_of = [&](int it) __attribute__((always_inline)) { return p.out + (long long)(team + (long long)it * n_teams) * n; };
+    unsigned char* const S0 = sbase;
+    unsigned char* const S1 = sbase + phase_bytes;
+    unsigned char* const S2 = sbase + 2 * (size_t)phase_bytes;
+
+    cpx<T> keep[NT][NK * EP];  // the hand-over of phases 2, 3
+
+    auto dma_column_tile = [&](const cpx<T>* inb, int t, int i0, int i1) __attribute__((always_inline)) {
+        int tid = tid_invariant;
+        FFT_OPAQUE(tid);
+        const int log2CPR = log2CA - log2V16;
+        const int c0 = column_block(t) << log2CA;
+        const cpx<T>* src = inb + ((long long)(tid >> log2CPR) << log2L2) + c0 + V16 * (tid & ((1 << log2CPR) - 1));
+        const long long step = (long long)(nthreads >> log2CPR) << log2L2;
+        FFT_UNROLL
+        for (int i = 0; i < NCH; i++)
+            if (i >= i0 && i < i1) FFT_DMA16(src + i * step, land, land_lds, (unsigned)(i * nthreads + tid) * 16u);
+    };
+    auto dma_row_tile = [&](const unsigned char* sb, int i0, int i1) __attribute__((always_inline)) {
+        int tid = tid_invariant;
+        FFT_OPAQUE(tid);
+        const unsigned char* src = sb + (size_t)c * tile_bytes + (size_t)tid * 16;
+        FFT_UNROLL
+        for (int i = 0; i < NCH; i++)
+            if (i >= i0 && i < i1) FFT_DMA16_L2(src + (size_t)i * nthreads * 16, land, land_lds, (unsigned)(i * nthreads + tid) * 16u);
+    };
+    // chunks of a landing DMA issued from slot s of a tile with `total` slots: two halves from slots 0 and 1
+    auto slot_i0 = [&](int s) __attribute__((always_inline)) { return s == 0 ? 0 : p.dma_split; };
+    auto slot_i1 = [&](int s, int total) __attribute__((always_inline)) { return s == 0 ? (total >= 2 ? p.dma_split : NCH) : NCH; };
+    // hand over phase ph (2 or 3) from the kept registers into window `sb`, all four column tiles
+    auto hand_over_kept = [&](unsigned char* sb, int ph, int rA, int jA) __attribute__((always_inline)) {
+        const bool third = (ph == 3);
+        FFT_UNROLL
+        for (int tt = 0; tt < NT; tt++) {
+            cpx<T> y[EP];
+            FFT_UNROLL
+            for (int ee = 0; ee < EP; ee++) {  // value by value (see pair_rows)
+                const cpx<T> a = keep[tt][ee], b3 = keep[tt][EP + ee];
+                y[ee] = mk<T>(third ? b3.re : a.re, third ? b3.im : a.im);
+            }
+            team_hand_over<T, EP>(sb, y, (column_block(tt) << log2CA) + jA, rA, log2TPCA, log2CB, tile_bytes, 1 << log2CA);
+        }
+    };
+    // one row phase: the tile has landed; stages with `traffic(s, total)` in their slots; transposed result store
+    auto row_body = [&](cpx<T>* outb, int ph, auto&& traffic) __attribute__((always_inline)) {
+        int tid = tid_invariant;
+        FFT_OPAQUE(tid);
+        const int jB = tid & ((1 << log2CB) - 1), rB = tid >> log2CB;
+        cpx<T> x[1][E][1];
+        team_all_stages<T, E>(x, land, work, twB, rB, jB, log2CB, log2TPCB, log2L2, traffic, false);
+        const long long k1 = ((long long)ph << (log2L1 - log2NT)) + ((long long)c << log2CB);
+        if (p.inverse) {
+            FFT_UNROLL
+            for (int e = 0; e < E; e++) x[0][e][0] = cswap(x[0][e][0]);
+        }
+        if (p.scale != (T)1) {
+            FFT_UNROLL
+            for (int e = 0; e < E; e++) x[0][e][0] = cscale(x[0][e][0], p.scale);
+        }
+        if constexpr (V16 == 2) {
+            const bool odd = (jB & 1) != 0;
+            FFT_UNROLL
+            for (int q = 0; q < E / 2; q++) {
+                const long long K = rB + (((2 * q) + (odd ? 1 : 0)) << log2TPCB);
+                vec16<T> v;
+                pair_rows<T>(x[0][2 * q][0], x[0][2 * q + 1][0], odd, 1, v);
+                *reinterpret_cast<vec16<T>*>(outb + (K << log2L1) + k1 + (jB & ~1)) = v;
+            }
+        } else {
+            FFT_UNROLL
+            for (int e = 0; e < E; e++) {
+                const long long K = rB + (e << log2TPCB);
+                *reinterpret_cast<cpx<T>*>(outb + (K << log2L1) + k1 + jB) = x[0][e][0];
+            }
+        }
+        ev();
+    };
+
+    dma_column_tile(in_of(0), 0, 0, NCH);
+    for (int it = 0; it < M; it++) {
+        const cpx<T>* inb = in_of(it);
+        cpx<T>* outb = out_of(it);
+        const int G = 4 * it;  // this transform's arrivals are G + 1 .. G + 4
+        int tid = tid_invariant;
+        FFT_OPAQUE(tid);
+        const int jA = tid & ((1 << log2CA) - 1), rA = tid >> log2CA;
+
+        // ================= column step; under its last tile the deferred row tile (phase 3 of it-1) is fetched
+        FFT_NOUNROLL
+        for (int t = 0; t < NT; t++) {
+            cpx<T> x[1][E][1];
+            FFT_WAIT_VM0();
+            FFT_SYNC_LDS();
+            team_all_stages<T, E>(x, land, work, twA, rA, jA, log2CA, log2TPCA, log2L1, [&](int s, int total) {
+                if (s > 1) return;
+                if (t + 1 < NT) {
+                    dma_column_tile(inb, t + 1, slot_i0(s), slot_i1(s, total));
+                } else if (it > 0) {
+                    if (s == 0) wait_all(G);  // X4 of it-1: everybody's hand-over of its phase 3 is in L2
+                    dma_row_tile(S2, slot_i0(s), slot_i1(s, total));
+                }
+            }, p.inverse != 0);
+            {
+                const cpx<T>* t0 = tab + p.o_t0;
+                const cpx<T>* t1 = tab + p.o_t1;
+                const unsigned m0 = (1u << p.t0_bits) - 1u;
+                const unsigned c0 = (unsigned)(column_block(t) << log2CA);
+                FFT_UNROLL
+                for (int e = 0; e < E; e++) {
+                    const unsigned m = (unsigned)(rA + (e << log2TPCA)) * (c0 + jA);
+                    x[0][e][0] = cmul(x[0][e][0], cmul(t0[m & m0], t1[m >> p.t0_bits]));
+                }
+            }
+            if (t == 0 && it > 0) wait_all(G);  // S0 / S1 were last read by row tiles 2 / 1 of it-1 (X4 covers both)
+            FFT_UNROLL
+            for (int ph = 0; ph < 2; ph++) {
+                cpx<T> y[EP];
+                FFT_UNROLL
+                for (int ee = 0; ee < EP; ee++) y[ee] = x[0][ph * EP + ee][0];
+                team_hand_over<T, EP>(ph ? S1 : S0, y, (column_block(t) << log2CA) + jA, rA, log2TPCA, log2CB, tile_bytes, 1 << log2CA);
+            }
+            FFT_UNROLL
+            for (int tt = 0; tt < NT; tt++) {
+                if (t == tt) {
+                    FFT_UNROLL
+                    for (int k = 0; k < NK * EP; k++) keep[tt][k] = x[0][2 * EP + k][0];
+                }
+            }
+            ev();
+        }
+        FFT_WAIT_VM0();
+        FFT_SYNC_LDS();
+        arrive(G + 1);  // X1
+
+        // ================= the turn: the deferred phase 3 of it-1 runs while X1 spreads and row tile 0 makes its trip
+        if (it > 0) {
+            row_body(out_of(it - 1), 3, [&](int s, int total) {
+                if (s > 1) return;
+                if (s == 0) wait_all(G + 1);
+                dma_row_tile(S0, slot_i0(s), slot_i1(s, total));
+            });
+            FFT_WAIT_VM_LE(NCH);  // everything but the deferred phase's result stores: row tile 0 has landed
+        } else {
+            wait_all(G + 1);
+            dma_row_tile(S0, 0, NCH);
+            FFT_WAIT_VM0();
+        }
+        FFT_SYNC_LDS();
+        arrive(G + 2);  // X2
+
+        // ================= row phases 0, 1, 2 of this transform
+        row_body(outb, 0, [&](int s, int total) {
+            if (s <= 1) dma_row_tile(S1, slot_i0(s), slot_i1(s, total));  // phase 1: in L2 since X1
+            if (s == (total >= 2 ? 1 : 0)) {
+                wait_all(G + 2);  // everybody has read row tile 0: S0 takes phase 2
+                hand_over_kept(S0, 2, rA, jA);
+            }
+        });
+        FFT_WAIT_VM_LE(NCH);
+        FFT_SYNC_LDS();
+        arrive(G + 3);  // X3
+        row_body(outb, 1, [&](int s, int total) {
+            if (s > 1) return;
+            if (s == 0) wait_all(G + 3);
+            dma_row_tile(S0, slot_i0(s), slot_i1(s, total));
+            // S2 was last read by the deferred row tile, landed everywhere since X1
+            if (s == (total >= 2 ? 1 : 0)) hand_over_kept(S2, 3, rA, jA);
+        });
+        FFT_WAIT_VM_LE(NCH);
+        FFT_SYNC_LDS();
+        arrive(G + 4);  // X4
+        row_body(outb, 2, [&](int s, int total) {
+            if (s > 1) return;
+            if (it + 1 < M) {
+                dma_column_tile(in_of(it + 1), 0, slot_i0(s), slot_i1(s, total));
+            } else {  // the last transform fetches its own phase 3 right away
+                if (s == 0) wait_all(G + 4);
+                dma_row_tile(S2, slot_i0(s), slot_i1(s, total));
+            }
+        });
+    }
+    // ================= phase 3 of the last transform
+    FFT_WAIT_VM0();
+    FFT_SYNC_LDS();
+    row_body(out_of(M - 1), 3, [&](int, int) {});
+}
+
+}  // namespace fftk

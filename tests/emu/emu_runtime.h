@@ -35,6 +35,7 @@ struct Runtime {
         return true;
     }
     bool team_default_on(int, int) { return true; }
+    bool team_defer(int, int) { return getenv("FFT_EMU_TEAM_PLAIN") == nullptr; }  // the shipped default; FFT_EMU_TEAM_PLAIN: team_fft_kernel
     bool team_asplit(int, int) { return getenv("FFT_EMU_TEAM_ASPLIT") != nullptr; }
     long long team_timeout_ticks() { return 60ll * 100000000ll; }
     int team_grid_skew() { return (team_mode >> 20) & 1; }

@@ -125,8 +125,13 @@ TEAM_CASES = [
 ]
 
 
+@pytest.mark.parametrize("plain", [False, True])
 @pytest.mark.parametrize("n,batch,dtype,log2seats,n_xcc,threads,lds,tiles", TEAM_CASES)
-def test_team_kernel(n, batch, dtype, log2seats, n_xcc, threads, lds, tiles):
+def test_team_kernel(n, batch, dtype, log2seats, n_xcc, threads, lds, tiles, plain, monkeypatch):
+    """plain=False: team_defer_kernel where it applies (four tiles: the shipped default; the last row phase of a transform
+    runs after the next one's column step), plain=True: team_fft_kernel."""
+    if plain:
+        monkeypatch.setenv("FFT_EMU_TEAM_PLAIN", "1")
     x = O.gen_lcg(n, 1, batch).astype(dtype)
     for d in (-1, 1):
         for inplace in (False, True):

@@ -640,6 +640,38 @@ def test_team_kernels_of_two_plans_on_two_streams(gpu_lib, monkeypatch):
         b.free()
 
 
+def test_team_kernel_plain_variant(gpu_lib):
+    """FFT_HIP_TEAM_DEFER=0: team_fft_kernel (the schedule without the deferred row phase) stays parity-green; the
+    variable is read once per process, hence the fresh one."""
+    import subprocess
+    import sys
+    code = (
+        "import os, sys, numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import fftlib, oracle_lib as O\n"
+        "fftlib.init()\n"
+        "for log2n, dt in ((20, np.complex64), (18, np.complex64), (17, np.complex128)):\n"
+        "    n, batch = 1 << log2n, 70\n"
+        "    x = O.gen_lcg(n, 33, batch).astype(dt)\n"
+        "    buf = fftlib.DeviceBuffer(x.nbytes)\n"
+        "    for d in (-1, 1):\n"
+        "        p = fftlib.Plan(n, batch, d, dt)\n"
+        "        buf.upload(x); p.execute_ptr(buf.ptr, buf.ptr)\n"
+        "        assert p.team_status() == 0\n"
+        "        y = buf.download(x.shape, dt)\n"
+        "        for b in (0, 33, 69):\n"
+        "            ref = O.oracle_fft(x[b:b+1].astype(np.complex128), d, 'dit')\n"
+        "            r = float(np.linalg.norm(y[b:b+1] - ref) / np.linalg.norm(ref))\n"
+        "            assert r < (2e-6 if dt == np.complex64 else 2e-11), (log2n, d, b, r)\n"
+        "        p.destroy()\n"
+        "    buf.free()\n"
+        "print('ok')\n"
+    ) % (os.path.join(ROOT, "fft-implementation-in-c_amd"), os.path.join(ROOT, "tests"))
+    env = dict(os.environ, FFT_HIP_TEAM="2", FFT_HIP_TEAM_DEFER="0")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
+
+
 def test_team_kernel_even_odd_row_split(gpu_lib, monkeypatch):
     """FFT_HIP_TEAM_ASPLIT=1: the column step of n = 2^20 fp32 on half-height, double-width tiles (128-byte row
     segments) joined by a radix-2 butterfly in registers -- an experiment (slower than the plain tiles), kept
