@@ -326,7 +326,7 @@ def main():
     per_pass = []
     if not info.bluestein_m:
         prof = [plan.profile_passes(x.data_ptr(), y.data_ptr(), 6) for _ in range(3)][-1]
-        names = (["team_fft_kernel"] + ["fallback pass %d (returns at once)" % i for i in range(8)]) if team else \
+        names = (["team kernel (team_defer_kernel; team_fft_kernel with FFT_HIP_TEAM_DEFER=0)"] + ["fallback pass %d (returns at once)" % i for i in range(8)]) if team else \
                 ["tile_fft_kernel pass %d" % i for i in range(8)]
         per_pass = [{"pass": i, "kernel": names[i], "launches_per_step": c, "avg_launch_ms": m / c, "ms_per_step": m}
                     for i, (m, c) in enumerate(prof)]
@@ -347,7 +347,7 @@ def main():
         n_groups, units_per_launch = 1, batch
         team_ms = per_pass[0]["avg_launch_ms"] if per_pass else ev_ms_per_step
         achieved = bytes_alg_per_step_gpu / (team_ms * 1e-3) / 1e9
-        kernel_desc = ("team_fft_kernel: ONE launch per step transforms all %d transforms, a whole transform per XCD "
+        kernel_desc = ("team_defer_kernel (csrc/fft_team_defer.h): ONE launch per step transforms all %d transforms, a whole transform per XCD "
                        "(256 workgroups = 8 teams of 32, %d tiles per workgroup and step); the %d multi-pass launches "
                        "queued behind it as its fallback return at once" % (batch, info.team_tiles, launches))
     else:
@@ -397,7 +397,7 @@ def main():
             "per_pass": per_pass,
             "hip_event_ms_per_step": ev_ms_per_step,
             "note": "achieved = 2*N*sizeof(complex) bytes per transform x transforms per launch set / HIP-event duration "
-                    "of the set (events on the plan's stream, rank 0; team schedule: of the team_fft_kernel launch alone); per_pass = live "
+                    "of the set (events on the plan's stream, rank 0; team schedule: of the team kernel's launch alone); per_pass = live "
                     "HIP-event time of each launch; "
                     "traffic: " + traffic_note,
         },
