@@ -70,6 +70,7 @@ inline T shfl_xor_any(T v, int mask) {
 #define FFT_DMA16(gsrc, lds_base_ptr, lds_base_addr, off) memcpy((lds_base_ptr) + (off), (gsrc), 16)
 #define FFT_DMA16_L2(gsrc, lds_base_ptr, lds_base_addr, off) memcpy((lds_base_ptr) + (off), (gsrc), 16)
 #define FFT_DMA16_NT(gsrc, lds_base_ptr, lds_base_addr, off) memcpy((lds_base_ptr) + (off), (gsrc), 16)
+#define FFT_DMA16_L2_NT(gsrc, lds_base_ptr, lds_base_addr, off) memcpy((lds_base_ptr) + (off), (gsrc), 16)
 #define FFT_STORE16_NT(ptr, v) (*(ptr) = (v))
 #define FFT_WAIT_VM_LE(n) __atomic_thread_fence(__ATOMIC_SEQ_CST)
 #else
@@ -133,6 +134,7 @@ inline T shfl_xor_any(T v, int mask) {
 #define FFT_DMA16(gsrc, lds_base_ptr, lds_base_addr, off) fft_dma16<0>((gsrc), (lds_base_addr) + (unsigned)(off))
 #define FFT_DMA16_L2(gsrc, lds_base_ptr, lds_base_addr, off) fft_dma16<1>((gsrc), (lds_base_addr) + (unsigned)(off))
 #define FFT_DMA16_NT(gsrc, lds_base_ptr, lds_base_addr, off) fft_dma16<2>((gsrc), (lds_base_addr) + (unsigned)(off))
+#define FFT_DMA16_L2_NT(gsrc, lds_base_ptr, lds_base_addr, off) fft_dma16<3>((gsrc), (lds_base_addr) + (unsigned)(off))
 // 16-byte store with the non-temporal (streaming) hint: the line is the first to leave the L2
 #define FFT_STORE16_NT(ptr, v) fft_store16_nt((ptr), (v))
 typedef unsigned fft_u32x4 __attribute__((ext_vector_type(4)));
@@ -141,7 +143,8 @@ __device__ __forceinline__ void fft_store16_nt(V16* ptr, const V16& v) {
     static_assert(sizeof(V16) == 16, "one 16-byte lane access");
     fft_u32x4 raw;
     __builtin_memcpy(&raw, &v, 16);
-    __builtin_nontemporal_store(raw, reinterpret_cast<fft_u32x4*>(ptr));
+    // hand-written: __builtin_nontemporal_store of a 16-byte vector comes out as a plain global_store_dwordx4 here
+    asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(ptr), "v"(raw) : "memory");
 }
 #define FFT_WAIT_VM_LE(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")  // at most n of my memory operations still in flight
 template <int SC1>
@@ -155,6 +158,9 @@ __device__ __forceinline__ void fft_dma16(const void* gsrc, unsigned lane_lds_ad
                      : "=&s"(saved_m0) : "v"(gsrc), "s"(lds_addr) : "memory");
     else if (SC1 == 2)
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                     : "=&s"(saved_m0) : "v"(gsrc), "s"(lds_addr) : "memory");
+    else if (SC1 == 3)  // served by the shared L2, and the line is the first to leave it afterwards (read once)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off sc1 nt\n\ts_mov_b32 m0, %0"
                      : "=&s"(saved_m0) : "v"(gsrc), "s"(lds_addr) : "memory");
     else
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"

@@ -329,7 +329,9 @@ class Pow2Plan {
         tp.seat_rot = seat_rot;
         static const int tile_rot = getenv("FFT_HIP_TEAM_TILE_ROT") ? atoi(getenv("FFT_HIP_TEAM_TILE_ROT")) : 4;
         tp.tile_rot = tile_rot;
-        static const int nt_mask = getenv("FFT_HIP_TEAM_NT") ? atoi(getenv("FFT_HIP_TEAM_NT")) : 0;
+        // column-tile DMA with the non-temporal bit (read once: the first lines to leave the L2, which keeps more of the
+        // hand-over windows there): +1..3 % at every size; nt result stores and nt window loads measured even or worse
+        static const int nt_mask = getenv("FFT_HIP_TEAM_NT") ? atoi(getenv("FFT_HIP_TEAM_NT")) : 1;
         tp.nt_mask = nt_mask;
         static const int tune = getenv("FFT_HIP_TEAM_TUNE") ? atoi(getenv("FFT_HIP_TEAM_TUNE")) : 0;
         tp.tune = tune;

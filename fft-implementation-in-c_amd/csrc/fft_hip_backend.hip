@@ -108,10 +108,11 @@ struct HipRT {
         nthreads = 512;
         return true;
     }
-    // sizes where the team kernel measured faster than the multi-pass schedule: fp32 2^17..2^20
-    // (+8, +17, +13, +10 %), fp64 2^15..2^17 (+5, +2, +7 %); fp32 2^16 (-4 %) and fp64 2^18 / 2^19 (-3 / -8 %) stay multi-pass
+    // sizes where the team kernel measured faster than the multi-pass schedule (tools/team_sweep.py at 4 GiB
+    // per execute): fp32 2^17..2^20 (+14, +22, +18, +13 %), fp64 2^15..2^18 (+23, +22, +34, +17 %); fp32 2^16 (-4 %) and
+    // fp64 2^19 (+1..4 %, within the box-to-box spread) stay multi-pass
     bool team_default_on(int elem_bytes, int log2n) {
-        return elem_bytes == 8 ? (log2n >= 17 && log2n <= 20) : (log2n >= 15 && log2n <= 17);
+        return elem_bytes == 8 ? (log2n >= 17 && log2n <= 20) : (log2n >= 15 && log2n <= 18);
     }
     // the column step on 128-byte row segments (fft_team.h ASPLIT), instantiated for fp32 n = 2^20 where the plain
     // tiles have 64-byte ones.  Measured 125 vs 137 Gpoint/s (the joined halves concentrate twiddles and hand-over in
@@ -121,10 +122,12 @@ struct HipRT {
         return on && elem_bytes == 8 && log2n == 20;
     }
     // team_defer_kernel (fft_team_defer.h: the last row phase fills the turn of the next transform) instead of
-    // team_fft_kernel: +3..6 % at n = 2^20, 2^19 and fp64, even at 2^18, 2^17; FFT_HIP_TEAM_DEFER=0 keeps the plain kernel
-    bool team_defer(int /*elem_bytes*/, int /*log2n*/) {
-        static const int on = getenv("FFT_HIP_TEAM_DEFER") ? atoi(getenv("FFT_HIP_TEAM_DEFER")) : 1;
-        return on != 0;
+    // team_fft_kernel: +3..6 % at fp32 n = 2^20, 2^19 and +3..12 % for fp64; the small fp32 teams (2^17, 2^18: 4 and 8
+    // CUs wait little at the turn) are 2-3 % faster without the third window.  FFT_HIP_TEAM_DEFER=0 / 1 forces either.
+    bool team_defer(int elem_bytes, int log2n) {
+        static const int forced = getenv("FFT_HIP_TEAM_DEFER") ? atoi(getenv("FFT_HIP_TEAM_DEFER")) : -1;
+        if (forced >= 0) return forced != 0;
+        return elem_bytes == 16 || log2n >= 19;
     }
     long long team_timeout_ticks() { return 20000000ll; }  // 0.2 s of the 100 MHz wall clock
     template <class K, class... A>

@@ -70,12 +70,12 @@ struct TeamParams {
     int sa1_bits, sa2_bits, t0_bits;
     long long timeout_ticks;  // bound of every spin, in FFT_CLOCK ticks
     int tune;                 // experiments: bit 0 hand-over of phase 2 from the first hook of phase 0 too
-    int nt_mask;              // cache policy of the HBM streams: bit 0 column-tile DMA nt, bit 1 result stores nt
+    int nt_mask;              // cache policy: bit 0 column-tile DMA nt, bit 1 result stores nt, bit 2 window loads sc1 nt (read once)
     int force_no_teams;       // tests: pretend the placement check failed (exercises the two-pass fallback)
     int tile_rot;             // column_block(): seats rotate by this many blocks per tile
     int seat_rot;             // experiments: seat = (registration order + seat_rot) mod TS
     int dma_split, dma_split2;  // column-tile DMA: chunks [0, dma_split) go out from slot 0, [dma_split, dma_split2) from slot 1, the rest from slot 2
-    int ablate;               // experiments: 1 skip the inter-pass twiddle, 2 skip the stages
+    int ablate;               // experiments: 1 skip the inter-pass twiddle, 2 skip the stages, 4 no result stores, 8 no column-tile DMA
     long long* trace;         // profiling: not NULL = every workgroup logs FFT_CLOCK at its first trace_events events
     int trace_events;
     T scale;
@@ -357,7 +357,7 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
         const long long step = (long long)(nthreads >> log2CPR) << log2L2;  // rows per wave-front of chunks
         FFT_UNROLL
         for (int i = 0; i < NCH; i++)
-            if (i >= i0 && i < i1) {
+            if (i >= i0 && i < i1 && !(p.ablate & 8)) {  // ablate 8 (profiling): no input stream
                 if (p.nt_mask & 1) FFT_DMA16_NT(src + i * step, land, land_lds, (unsigned)(i * nthreads + tid) * 16u);
                 else FFT_DMA16(src + i * step, land, land_lds, (unsigned)(i * nthreads + tid) * 16u);
             }
@@ -369,7 +369,8 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
         const unsigned char* src = sb + (size_t)c * tile_bytes + (size_t)tid * 16;
         FFT_UNROLL
         for (int i = 0; i < NCH; i++)
-            FFT_DMA16_L2(src + (size_t)i * nthreads * 16, land, land_lds, (unsigned)(i * nthreads + tid) * 16u);
+            if (p.nt_mask & 4) FFT_DMA16_L2_NT(src + (size_t)i * nthreads * 16, land, land_lds, (unsigned)(i * nthreads + tid) * 16u);
+            else FFT_DMA16_L2(src + (size_t)i * nthreads * 16, land, land_lds, (unsigned)(i * nthreads + tid) * 16u);
     };
     // column tile t covers columns [column_block(t) * CA, + CA); ASPLIT: half tile t = (group t / 2, row parity t % 2)
     // covers the 2 CA columns [column_group(t / 2) * 2 CA, + 2 CA)
@@ -614,6 +615,7 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
                     vec16<T> v;
                     pair_rows<T>(x[0][2 * q][0], x[0][2 * q + 1][0], odd, 1, v);
                     vec16<T>* dst = reinterpret_cast<vec16<T>*>(outb + (K << log2L1) + k1 + (jB & ~1));
+                    if (p.ablate & 4) continue;  // profiling: no result stream
                     if (p.nt_mask & 2) FFT_STORE16_NT(dst, v);
                     else *dst = v;
                 }

@@ -151,7 +151,10 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
         const long long step = (long long)(nthreads >> log2CPR) << log2L2;
         FFT_UNROLL
         for (int i = 0; i < NCH; i++)
-            if (i >= i0 && i < i1) FFT_DMA16(src + i * step, land, land_lds, (unsigned)(i * nthreads + tid) * 16u);
+            if (i >= i0 && i < i1) {
+                if (p.nt_mask & 1) FFT_DMA16_NT(src + i * step, land, land_lds, (unsigned)(i * nthreads + tid) * 16u);
+                else FFT_DMA16(src + i * step, land, land_lds, (unsigned)(i * nthreads + tid) * 16u);
+            }
     };
     auto dma_row_tile = [&](const unsigned char* sb, int i0, int i1) __attribute__((always_inline)) {
         int tid = tid_invariant;
@@ -159,7 +162,10 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
         const unsigned char* src = sb + (size_t)c * tile_bytes + (size_t)tid * 16;
         FFT_UNROLL
         for (int i = 0; i < NCH; i++)
-            if (i >= i0 && i < i1) FFT_DMA16_L2(src + (size_t)i * nthreads * 16, land, land_lds, (unsigned)(i * nthreads + tid) * 16u);
+            if (i >= i0 && i < i1) {
+                if (p.nt_mask & 4) FFT_DMA16_L2_NT(src + (size_t)i * nthreads * 16, land, land_lds, (unsigned)(i * nthreads + tid) * 16u);
+                else FFT_DMA16_L2(src + (size_t)i * nthreads * 16, land, land_lds, (unsigned)(i * nthreads + tid) * 16u);
+            }
     };
     // chunks of a landing DMA issued from slot s of a tile with `total` slots: two halves from slots 0 and 1
     auto slot_i0 = [&](int s) __attribute__((always_inline)) { return s == 0 ? 0 : p.dma_split; };
@@ -201,7 +207,9 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
                 const long long K = rB + (((2 * q) + (odd ? 1 : 0)) << log2TPCB);
                 vec16<T> v;
                 pair_rows<T>(x[0][2 * q][0], x[0][2 * q + 1][0], odd, 1, v);
-                *reinterpret_cast<vec16<T>*>(outb + (K << log2L1) + k1 + (jB & ~1)) = v;
+                vec16<T>* dst = reinterpret_cast<vec16<T>*>(outb + (K << log2L1) + k1 + (jB & ~1));
+                if (p.nt_mask & 2) FFT_STORE16_NT(dst, v);
+                else *dst = v;
             }
         } else {
             FFT_UNROLL

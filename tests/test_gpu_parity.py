@@ -640,9 +640,12 @@ def test_team_kernels_of_two_plans_on_two_streams(gpu_lib, monkeypatch):
         b.free()
 
 
-def test_team_kernel_plain_variant(gpu_lib):
-    """FFT_HIP_TEAM_DEFER=0: team_fft_kernel (the schedule without the deferred row phase) stays parity-green; the
-    variable is read once per process, hence the fresh one."""
+@pytest.mark.parametrize("defer,nt", [("0", "0"), ("1", "0"), ("1", "7"), ("0", "7")])
+def test_team_kernel_forced_variants(gpu_lib, defer, nt):
+    """Both team kernels at every kind of size, whatever the per-size default is: FFT_HIP_TEAM_DEFER=0 team_fft_kernel,
+    =1 team_defer_kernel (the deferred row phase), with the default cache-policy bits off (FFT_HIP_TEAM_NT=0) and all
+    on (7: non-temporal column-tile DMA, result stores and window loads).  The variables are read once per process,
+    hence the fresh one."""
     import subprocess
     import sys
     code = (
@@ -650,7 +653,7 @@ def test_team_kernel_plain_variant(gpu_lib):
         "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
         "import fftlib, oracle_lib as O\n"
         "fftlib.init()\n"
-        "for log2n, dt in ((20, np.complex64), (18, np.complex64), (17, np.complex128)):\n"
+        "for log2n, dt in ((20, np.complex64), (18, np.complex64), (17, np.complex128), (18, np.complex128)):\n"
         "    n, batch = 1 << log2n, 70\n"
         "    x = O.gen_lcg(n, 33, batch).astype(dt)\n"
         "    buf = fftlib.DeviceBuffer(x.nbytes)\n"
@@ -667,7 +670,7 @@ def test_team_kernel_plain_variant(gpu_lib):
         "    buf.free()\n"
         "print('ok')\n"
     ) % (os.path.join(ROOT, "fft-implementation-in-c_amd"), os.path.join(ROOT, "tests"))
-    env = dict(os.environ, FFT_HIP_TEAM="2", FFT_HIP_TEAM_DEFER="0")
+    env = dict(os.environ, FFT_HIP_TEAM="2", FFT_HIP_TEAM_DEFER=defer, FFT_HIP_TEAM_NT=nt)
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
 
