@@ -62,6 +62,9 @@ inline T shfl_xor_any(T v, int mask) {
 #define FFT_ATOMIC_STORE_AGENT(p, v) __atomic_store_n((p), (v), __ATOMIC_SEQ_CST)
 #define FFT_L2_FLAG_STORE(p, v) __atomic_store_n((p), (v), __ATOMIC_SEQ_CST)
 #define FFT_L2_FLAG_LOAD(p) __atomic_load_n((p), __ATOMIC_SEQ_CST)
+#define FFT_L2_COUNT_ADD(p) ((void)__atomic_fetch_add((p), 1u, __ATOMIC_SEQ_CST))
+#define FFT_L2_COUNT_POLL(p) __atomic_load_n((p), __ATOMIC_SEQ_CST)
+#define FFT_LDS_FRESH() __atomic_thread_fence(__ATOMIC_SEQ_CST)
 #define FFT_WAIT_VM0() __atomic_thread_fence(__ATOMIC_SEQ_CST)
 #define FFT_SLEEP() sched_yield()
 #define FFT_CLOCK() emu::clock_ticks()
@@ -114,8 +117,23 @@ inline T shfl_xor_any(T v, int mask) {
 #define FFT_ATOMIC_STORE_AGENT(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT)
 // Same-XCD signalling through the XCD's own L2: a PLAIN dword store stays in L2 (write-through L1), an sc1 load
 // bypasses the reader's L1 and is served by that L2.  Valid ONLY between workgroups that read the same XCC id.
-#define FFT_L2_FLAG_STORE(p, v) (*(volatile unsigned*)(p) = (v))
+// (hand-written: a volatile C store comes out as flat_store_dword sc0 sc1, i.e. written through to memory)
+#define FFT_L2_FLAG_STORE(p, v) asm volatile("global_store_dword %0, %1, off" ::"v"((unsigned*)(p)), "v"((unsigned)(v)) : "memory")
 #define FFT_L2_FLAG_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+// Arrival counter of a team in the XCD's L2: the add is performed by the L2 (no return value, nothing to wait for);
+// the poll is a SCALAR load (glc: past the scalar cache, served by that L2).  A vector load would do, but its result
+// could only be looked at behind `s_waitcnt vmcnt(0)`, i.e. behind every store and LDS-DMA the wave still has in
+// flight -- a poll that drains the memory pipeline it is supposed to let run.  Scalar loads count on lgkmcnt.
+#define FFT_L2_COUNT_ADD(p) asm volatile("global_atomic_add %0, %1, off" ::"v"((unsigned*)(p)), "v"(1u) : "memory")
+#define FFT_L2_COUNT_POLL(p) fft_scalar_load_glc((const unsigned*)(p))
+__device__ __forceinline__ unsigned fft_scalar_load_glc(const unsigned* p) {
+    unsigned v;
+    asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+    return v;
+}
+// the next read of a (non-volatile) LDS word is a real ds_read: volatile accesses through a pointer whose address
+// space the compiler has to infer come out as FLAT loads, which wait on vmcnt as well
+#define FFT_LDS_FRESH() asm volatile("" ::: "memory")
 #define FFT_WAIT_VM0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #define FFT_SLEEP() __builtin_amdgcn_s_sleep(2)
 #define FFT_CLOCK() ((long long)wall_clock64())

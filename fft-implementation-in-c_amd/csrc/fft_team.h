@@ -259,7 +259,7 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
         for (int i = tid_invariant; i < (p.tables_bytes >> 4); i += nthreads) dst[i] = src[i];
     }
     const cpx<T>* tab = reinterpret_cast<const cpx<T>*>(tab_bytes);
-    volatile unsigned* sh = reinterpret_cast<volatile unsigned*>(tab_bytes + p.tables_bytes);
+    unsigned* const sh = reinterpret_cast<unsigned*>(tab_bytes + p.tables_bytes);  // [slot, xcc, ok, timed out]
     // stage tables: single-level up to 8 KiB (fp32) / 4 KiB (fp64), else two-level -- TeamStageTable is the rule the
     // planner lays the blob out by; decided from the (baked-in) geometry, so no per-lookup branch survives
     StageTw<T> twA, twB;
@@ -300,6 +300,7 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
         sh[3] = 0;  // set when a team wait timed out: later waits return at once, the status word tells the host
     }
     FFT_SYNC();
+    FFT_LDS_FRESH();
     if (!sh[2]) return;
     // seats of an XCD in registration order; consecutive runs of TS seats form the teams of that XCD
     const unsigned seat = (FFT_UNIFORM(sh[0]) + (unsigned)p.seat_rot) & ((1u << p.log2seats) - 1u);
@@ -320,22 +321,34 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
     ev();  // 0: team formed
     if (p.trace && tid_invariant == 0 && p.trace_events > 1) p.trace[(long long)FFT_BID * p.trace_events + p.trace_events - 1] = (team << 8) | c;
 
-    // every member has stored generation >= g on the team's flag line (polled by each wave for itself)
+    // Arrivals.  NT == 4: every member waits for everybody's arrival g before its own arrival g + 1 (see the table
+    // above the kernel), so ONE counter per team says it all: everybody has arrived at g <=> count >= TS * g.  The first
+    // wave polls it with scalar loads (FFT_L2_COUNT_POLL: not behind the wave's stores and DMA), the others wait at the
+    // workgroup barrier.  NT < 4 (tests): one generation word per member, polled with a vector load of the flag line.
+    constexpr bool COUNTER = (NT == 4);
     auto wait_all = [&](unsigned g) __attribute__((always_inline)) {
+        FFT_LDS_FRESH();
         if (sh[3]) return;
-        const long long t0 = FFT_CLOCK();
-        while (!team_all_arrived(flags, TS, g, tid_invariant & (FFT_TEAM_POLL_LANES - 1))) {
-            if (FFT_CLOCK() - t0 > p.timeout_ticks) {
-                FFT_ATOMIC_STORE_AGENT(&p.ctl[TEAM_CTL_STATUS], (unsigned)TEAM_STATUS_TIMEOUT);
-                sh[3] = 1;
-                break;
+        if (tid_invariant < FFT_TEAM_POLL_LANES) {
+            const long long t0 = FFT_CLOCK();
+            while (COUNTER ? (int)(((p.tune & 2) ? FFT_L2_FLAG_LOAD(flags) : FFT_L2_COUNT_POLL(flags)) - (g << log2TS)) < 0
+                           : !team_all_arrived(flags, TS, g, tid_invariant & (FFT_TEAM_POLL_LANES - 1))) {
+                if (FFT_CLOCK() - t0 > p.timeout_ticks) {
+                    FFT_ATOMIC_STORE_AGENT(&p.ctl[TEAM_CTL_STATUS], (unsigned)TEAM_STATUS_TIMEOUT);
+                    sh[3] = 1;
+                    break;
+                }
+                FFT_SLEEP();
             }
-            FFT_SLEEP();
         }
+        FFT_SYNC_LDS();
     };
     // call with every wave's relevant memory operations complete and behind a workgroup barrier
     auto arrive = [&](unsigned g) __attribute__((always_inline)) {
-        if (tid_invariant == 0) FFT_L2_FLAG_STORE(&flags[c], g);
+        if (tid_invariant == 0) {
+            if (COUNTER) FFT_L2_COUNT_ADD(flags);
+            else FFT_L2_FLAG_STORE(&flags[c], g);
+        }
     };
 
     cpx<T> keep[NT][NK * EP + 1];  // [tile][slot - 2*EP]: the hand-over of phases >= 2

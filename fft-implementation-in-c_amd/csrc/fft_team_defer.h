@@ -58,7 +58,7 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
         for (int i = tid_invariant; i < (p.tables_bytes >> 4); i += nthreads) dst[i] = src[i];
     }
     const cpx<T>* tab = reinterpret_cast<const cpx<T>*>(tab_bytes);
-    volatile unsigned* sh = reinterpret_cast<volatile unsigned*>(tab_bytes + p.tables_bytes);
+    unsigned* const sh = reinterpret_cast<unsigned*>(tab_bytes + p.tables_bytes);  // [slot, xcc, ok, timed out]
     StageTw<T> twA, twB;
     twA.sa = tab;
     twA.sb = tab + p.o_sb1;
@@ -97,6 +97,7 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
         sh[3] = 0;
     }
     FFT_SYNC();
+    FFT_LDS_FRESH();
     if (!sh[2]) return;
     const unsigned seat = (FFT_UNIFORM(sh[0]) + (unsigned)p.seat_rot) & ((1u << p.log2seats) - 1u);
     const int c = (int)(seat & (unsigned)(TS - 1));
@@ -118,20 +119,26 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
     ev();
     if (p.trace && tid_invariant == 0 && p.trace_events > 1) p.trace[(long long)FFT_BID * p.trace_events + p.trace_events - 1] = (team << 8) | c;
 
+    // everybody has arrived at g <=> the team's counter >= TS * g: every member waits for everybody's X(g) before its own
+    // X(g + 1).  Polled by the first wave with scalar loads (see FFT_L2_COUNT_POLL), the others wait at the barrier.
     auto wait_all = [&](int g) __attribute__((always_inline)) {
+        FFT_LDS_FRESH();
         if (g <= 0 || sh[3]) return;
-        const long long t0 = FFT_CLOCK();
-        while (!team_all_arrived(flags, TS, (unsigned)g, tid_invariant & (FFT_TEAM_POLL_LANES - 1))) {
-            if (FFT_CLOCK() - t0 > p.timeout_ticks) {
-                FFT_ATOMIC_STORE_AGENT(&p.ctl[TEAM_CTL_STATUS], (unsigned)TEAM_STATUS_TIMEOUT);
-                sh[3] = 1;
-                break;
+        if (tid_invariant < FFT_TEAM_POLL_LANES) {
+            const long long t0 = FFT_CLOCK();
+            while ((int)(((p.tune & 2) ? FFT_L2_FLAG_LOAD(flags) : FFT_L2_COUNT_POLL(flags)) - ((unsigned)g << log2TS)) < 0) {  // tune bit 1: vector poll (experiment)
+                if (FFT_CLOCK() - t0 > p.timeout_ticks) {
+                    FFT_ATOMIC_STORE_AGENT(&p.ctl[TEAM_CTL_STATUS], (unsigned)TEAM_STATUS_TIMEOUT);
+                    sh[3] = 1;
+                    break;
+                }
+                FFT_SLEEP();
             }
-            FFT_SLEEP();
         }
+        FFT_SYNC_LDS();
     };
-    auto arrive = [&](int g) __attribute__((always_inline)) {
-        if (tid_invariant == 0) FFT_L2_FLAG_STORE(&flags[c], (unsigned)g);
+    auto arrive = [&](int) __attribute__((always_inline)) {
+        if (tid_invariant == 0) FFT_L2_COUNT_ADD(flags);
     };
     auto column_block = [&](int t) __attribute__((always_inline)) { return (t << log2TS) + ((c + p.tile_rot * t) & (TS - 1)); };
     auto in_of = [&](int it) __attribute__((always_inline)) { return p.in + (long long)(team + (long long)it * n_teams) * n; };

@@ -45,6 +45,12 @@ def main():
         row = []
         ms, info = run(log2n, dtype, {"FFT_HIP_TEAM": "0"})
         row.append("multi-pass %.1f" % (n * batch / ms / 1e6))
+        if os.environ.get("SWEEP_QUICK"):  # the shipped defaults only (plus whatever knobs the caller exported), three times
+            for _ in range(3):
+                ms, info = run(log2n, dtype, {"FFT_HIP_TEAM": "2"})
+                row.append("default %s" % ("%.1f" % (n * batch / ms / 1e6) if ms else "fail"))
+            print("2^%d %s x %d [Gpoint/s]: %s" % (log2n, dtype, batch, " | ".join(row)), flush=True)
+            continue
         for defer in (1, 0):
             for nt in (0, 1, 3, 7):
                 ms, info = run(log2n, dtype, {"FFT_HIP_TEAM": "2", "FFT_HIP_TEAM_DEFER": str(defer), "FFT_HIP_TEAM_NT": str(nt)})
