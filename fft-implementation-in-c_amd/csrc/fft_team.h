@@ -74,7 +74,7 @@ struct TeamParams {
     int force_no_teams;       // tests: pretend the placement check failed (exercises the two-pass fallback)
     int tile_rot;             // column_block(): seats rotate by this many blocks per tile
     int seat_rot;             // experiments: seat = (registration order + seat_rot) mod TS
-    int dma_split, dma_split2;  // column-tile DMA: chunks [0, dma_split) go out from slot 0, [dma_split, dma_split2) from slot 1, the rest from slot 2
+    int dma_split, dma_split2;  // (unused: the landing DMA goes out in two halves, from slots 0 and 1 -- compile-time, so that the chunk loop folds)
     int ablate;               // experiments: 1 skip the inter-pass twiddle, 2 skip the stages, 4 no result stores, 8 no column-tile DMA
     long long* trace;         // profiling: not NULL = every workgroup logs FFT_CLOCK at its first trace_events events
     int trace_events;
@@ -331,7 +331,7 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
         if (sh[3]) return;
         if (tid_invariant < FFT_TEAM_POLL_LANES) {
             const long long t0 = FFT_CLOCK();
-            while (COUNTER ? (int)(((p.tune & 2) ? FFT_L2_FLAG_LOAD(flags) : FFT_L2_COUNT_POLL(flags)) - (g << log2TS)) < 0
+            while (COUNTER ? (int)(FFT_L2_COUNT_POLL(flags) - (g << log2TS)) < 0
                            : !team_all_arrived(flags, TS, g, tid_invariant & (FFT_TEAM_POLL_LANES - 1))) {
                 if (FFT_CLOCK() - t0 > p.timeout_ticks) {
                     FFT_ATOMIC_STORE_AGENT(&p.ctl[TEAM_CTL_STATUS], (unsigned)TEAM_STATUS_TIMEOUT);
@@ -368,22 +368,31 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
         const int c0 = column_block(t) << log2CA;  // the team's workgroups read one contiguous TS*CA-column band
         const cpx<T>* src = inb + ((long long)(tid >> log2CPR) << log2L2) + c0 + V16 * (tid & ((1 << log2CPR) - 1));
         const long long step = (long long)(nthreads >> log2CPR) << log2L2;  // rows per wave-front of chunks
-        FFT_UNROLL
-        for (int i = 0; i < NCH; i++)
-            if (i >= i0 && i < i1 && !(p.ablate & 8)) {  // ablate 8 (profiling): no input stream
-                if (p.nt_mask & 1) FFT_DMA16_NT(src + i * step, land, land_lds, (unsigned)(i * nthreads + tid) * 16u);
-                else FFT_DMA16(src + i * step, land, land_lds, (unsigned)(i * nthreads + tid) * 16u);
-            }
+        if (p.ablate & 8) return;  // profiling: no input stream
+        if (p.nt_mask & 1) {  // one branch per call, not one per chunk
+            FFT_UNROLL
+            for (int i = 0; i < NCH; i++)
+                if (i >= i0 && i < i1) FFT_DMA16_NT(src + i * step, land, land_lds, (unsigned)(i * nthreads + tid) * 16u);
+        } else {
+            FFT_UNROLL
+            for (int i = 0; i < NCH; i++)
+                if (i >= i0 && i < i1) FFT_DMA16(src + i * step, land, land_lds, (unsigned)(i * nthreads + tid) * 16u);
+        }
     };
     // LDS-DMA of my row tile of the window `sb` (tile_bytes contiguous bytes), served by the XCD's L2
     auto dma_row_tile = [&](const unsigned char* sb) __attribute__((always_inline)) {
         int tid = tid_invariant;
         FFT_OPAQUE(tid);
         const unsigned char* src = sb + (size_t)c * tile_bytes + (size_t)tid * 16;
-        FFT_UNROLL
-        for (int i = 0; i < NCH; i++)
-            if (p.nt_mask & 4) FFT_DMA16_L2_NT(src + (size_t)i * nthreads * 16, land, land_lds, (unsigned)(i * nthreads + tid) * 16u);
-            else FFT_DMA16_L2(src + (size_t)i * nthreads * 16, land, land_lds, (unsigned)(i * nthreads + tid) * 16u);
+        if (p.nt_mask & 4) {
+            FFT_UNROLL
+            for (int i = 0; i < NCH; i++)
+                FFT_DMA16_L2_NT(src + (size_t)i * nthreads * 16, land, land_lds, (unsigned)(i * nthreads + tid) * 16u);
+        } else {
+            FFT_UNROLL
+            for (int i = 0; i < NCH; i++)
+                FFT_DMA16_L2(src + (size_t)i * nthreads * 16, land, land_lds, (unsigned)(i * nthreads + tid) * 16u);
+        }
     };
     // column tile t covers columns [column_block(t) * CA, + CA); ASPLIT: half tile t = (group t / 2, row parity t % 2)
     // covers the 2 CA columns [column_group(t / 2) * 2 CA, + 2 CA)
@@ -433,9 +442,8 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
                 const bool more = (t + 1 < NT);
                 team_all_stages<T, E>(x, land, work, twA, rA2, jA2, log2CA2, log2TPCA2, log2H1, [&](int s, int total) {
                     if (more) {
-                        if (s == 0) dma_half_tile(inb, t + 1, 0, total >= 2 ? p.dma_split : NCH);
-                        if (s == 1) dma_half_tile(inb, t + 1, p.dma_split, total >= 3 ? p.dma_split2 : NCH);
-                        if (s == 2) dma_half_tile(inb, t + 1, p.dma_split2, NCH);
+                        if (s == 0) dma_half_tile(inb, t + 1, 0, total >= 2 ? NCH / 2 : NCH);
+                        if (s == 1) dma_half_tile(inb, t + 1, NCH / 2, NCH);
                     }
                 }, p.inverse != 0);
                 if ((t & 1) == 0) {
@@ -490,9 +498,8 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
                 team_all_stages<T, E>(x, land, work, twA, rA, jA, log2CA, log2TPCA, log2L1, [&](int s, int total) {
                     // the next tile flies during the remaining stages; issued in two halves (a CU's memory queue is short)
                     if (more) {
-                        if (s == 0) dma_column_tile(inb, t + 1, 0, total >= 2 ? p.dma_split : NCH);
-                        if (s == 1) dma_column_tile(inb, t + 1, p.dma_split, total >= 3 ? p.dma_split2 : NCH);
-                        if (s == 2) dma_column_tile(inb, t + 1, p.dma_split2, NCH);
+                        if (s == 0) dma_column_tile(inb, t + 1, 0, total >= 2 ? NCH / 2 : NCH);
+                        if (s == 1) dma_column_tile(inb, t + 1, NCH / 2, NCH);
                     }
                 }, p.inverse != 0);  // inverse = forward transform between two re<->im swaps: first one here
             } else if (more) {
@@ -622,15 +629,18 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
             }
             if constexpr (V16 == 2) {
                 const bool odd = (jB & 1) != 0;
+                vec16<T> v[E / 2];
                 FFT_UNROLL
-                for (int q = 0; q < E / 2; q++) {
-                    const long long K = rB + (((2 * q) + (odd ? 1 : 0)) << log2TPCB);
-                    vec16<T> v;
-                    pair_rows<T>(x[0][2 * q][0], x[0][2 * q + 1][0], odd, 1, v);
-                    vec16<T>* dst = reinterpret_cast<vec16<T>*>(outb + (K << log2L1) + k1 + (jB & ~1));
-                    if (p.ablate & 4) continue;  // profiling: no result stream
-                    if (p.nt_mask & 2) FFT_STORE16_NT(dst, v);
-                    else *dst = v;
+                for (int q = 0; q < E / 2; q++) pair_rows<T>(x[0][2 * q][0], x[0][2 * q + 1][0], odd, 1, v[q]);
+                vec16<T>* const dst0 = reinterpret_cast<vec16<T>*>(outb + ((long long)(rB + ((odd ? 1 : 0) << log2TPCB)) << log2L1) + k1 + (jB & ~1));
+                const long long dstep = (2ll << (log2TPCB + log2L1)) / V16;  // two slots further on, in 16-byte units
+                if (p.ablate & 4) {  // profiling: no result stream
+                } else if (p.nt_mask & 2) {
+                    FFT_UNROLL
+                    for (int q = 0; q < E / 2; q++) FFT_STORE16_NT(dst0 + q * dstep, v[q]);
+                } else {
+                    FFT_UNROLL
+                    for (int q = 0; q < E / 2; q++) dst0[q * dstep] = v[q];
                 }
             } else {
                 FFT_UNROLL

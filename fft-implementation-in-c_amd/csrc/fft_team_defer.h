@@ -126,7 +126,7 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
         if (g <= 0 || sh[3]) return;
         if (tid_invariant < FFT_TEAM_POLL_LANES) {
             const long long t0 = FFT_CLOCK();
-            while ((int)(((p.tune & 2) ? FFT_L2_FLAG_LOAD(flags) : FFT_L2_COUNT_POLL(flags)) - ((unsigned)g << log2TS)) < 0) {  // tune bit 1: vector poll (experiment)
+            while ((int)(FFT_L2_COUNT_POLL(flags) - ((unsigned)g << log2TS)) < 0) {
                 if (FFT_CLOCK() - t0 > p.timeout_ticks) {
                     FFT_ATOMIC_STORE_AGENT(&p.ctl[TEAM_CTL_STATUS], (unsigned)TEAM_STATUS_TIMEOUT);
                     sh[3] = 1;
@@ -156,27 +156,33 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
         const int c0 = column_block(t) << log2CA;
         const cpx<T>* src = inb + ((long long)(tid >> log2CPR) << log2L2) + c0 + V16 * (tid & ((1 << log2CPR) - 1));
         const long long step = (long long)(nthreads >> log2CPR) << log2L2;
-        FFT_UNROLL
-        for (int i = 0; i < NCH; i++)
-            if (i >= i0 && i < i1) {
-                if (p.nt_mask & 1) FFT_DMA16_NT(src + i * step, land, land_lds, (unsigned)(i * nthreads + tid) * 16u);
-                else FFT_DMA16(src + i * step, land, land_lds, (unsigned)(i * nthreads + tid) * 16u);
-            }
+        if (p.nt_mask & 1) {  // one branch per call, not one per chunk
+            FFT_UNROLL
+            for (int i = 0; i < NCH; i++)
+                if (i >= i0 && i < i1) FFT_DMA16_NT(src + i * step, land, land_lds, (unsigned)(i * nthreads + tid) * 16u);
+        } else {
+            FFT_UNROLL
+            for (int i = 0; i < NCH; i++)
+                if (i >= i0 && i < i1) FFT_DMA16(src + i * step, land, land_lds, (unsigned)(i * nthreads + tid) * 16u);
+        }
     };
     auto dma_row_tile = [&](const unsigned char* sb, int i0, int i1) __attribute__((always_inline)) {
         int tid = tid_invariant;
         FFT_OPAQUE(tid);
         const unsigned char* src = sb + (size_t)c * tile_bytes + (size_t)tid * 16;
-        FFT_UNROLL
-        for (int i = 0; i < NCH; i++)
-            if (i >= i0 && i < i1) {
-                if (p.nt_mask & 4) FFT_DMA16_L2_NT(src + (size_t)i * nthreads * 16, land, land_lds, (unsigned)(i * nthreads + tid) * 16u);
-                else FFT_DMA16_L2(src + (size_t)i * nthreads * 16, land, land_lds, (unsigned)(i * nthreads + tid) * 16u);
-            }
+        if (p.nt_mask & 4) {
+            FFT_UNROLL
+            for (int i = 0; i < NCH; i++)
+                if (i >= i0 && i < i1) FFT_DMA16_L2_NT(src + (size_t)i * nthreads * 16, land, land_lds, (unsigned)(i * nthreads + tid) * 16u);
+        } else {
+            FFT_UNROLL
+            for (int i = 0; i < NCH; i++)
+                if (i >= i0 && i < i1) FFT_DMA16_L2(src + (size_t)i * nthreads * 16, land, land_lds, (unsigned)(i * nthreads + tid) * 16u);
+        }
     };
     // chunks of a landing DMA issued from slot s of a tile with `total` slots: two halves from slots 0 and 1
-    auto slot_i0 = [&](int s) __attribute__((always_inline)) { return s == 0 ? 0 : p.dma_split; };
-    auto slot_i1 = [&](int s, int total) __attribute__((always_inline)) { return s == 0 ? (total >= 2 ? p.dma_split : NCH) : NCH; };
+    auto slot_i0 = [&](int s) __attribute__((always_inline)) { return s == 0 ? 0 : NCH / 2; };
+    auto slot_i1 = [&](int s, int total) __attribute__((always_inline)) { return s == 0 ? (total >= 2 ? NCH / 2 : NCH) : NCH; };
     // hand over phase ph (2 or 3) from the kept registers into window `sb`, all four column tiles
     auto hand_over_kept = [&](unsigned char* sb, int ph, int rA, int jA) __attribute__((always_inline)) {
         const bool third = (ph == 3);
@@ -209,14 +215,17 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
         }
         if constexpr (V16 == 2) {
             const bool odd = (jB & 1) != 0;
+            vec16<T> v[E / 2];
             FFT_UNROLL
-            for (int q = 0; q < E / 2; q++) {
-                const long long K = rB + (((2 * q) + (odd ? 1 : 0)) << log2TPCB);
-                vec16<T> v;
-                pair_rows<T>(x[0][2 * q][0], x[0][2 * q + 1][0], odd, 1, v);
-                vec16<T>* dst = reinterpret_cast<vec16<T>*>(outb + (K << log2L1) + k1 + (jB & ~1));
-                if (p.nt_mask & 2) FFT_STORE16_NT(dst, v);
-                else *dst = v;
+            for (int q = 0; q < E / 2; q++) pair_rows<T>(x[0][2 * q][0], x[0][2 * q + 1][0], odd, 1, v[q]);
+            vec16<T>* const dst0 = reinterpret_cast<vec16<T>*>(outb + ((long long)(rB + ((odd ? 1 : 0) << log2TPCB)) << log2L1) + k1 + (jB & ~1));
+            const long long dstep = (2ll << (log2TPCB + log2L1)) / V16;  // two slots further on, in 16-byte units
+            if (p.nt_mask & 2) {
+                FFT_UNROLL
+                for (int q = 0; q < E / 2; q++) FFT_STORE16_NT(dst0 + q * dstep, v[q]);
+            } else {
+                FFT_UNROLL
+                for (int q = 0; q < E / 2; q++) dst0[q * dstep] = v[q];
             }
         } else {
             FFT_UNROLL
