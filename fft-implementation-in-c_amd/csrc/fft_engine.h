@@ -247,10 +247,11 @@ class Pow2Plan {
             return;
         }
         rt->h2d(d.tables, blob.data(), blob.size() * SZ);
-        // Below ~32 transforms per team the launch's fixed costs (team formation, pipeline fill, the last transforms of
-        // uneven teams) outweigh the saved HBM round trip: measured crossover with the two-pass schedule at batch ~200 of 2^20
-        // (2 GiB of data per execute: 256 transforms of 2^20 fp32, 1024 of 2^18, ...)
-        d.min_batch = mode == 1 ? (int)std::max<long long>(8ll * d.n_teams, (1ll << 31) / ((long long)SZ << log2n)) : d.n_teams;
+        // Small executes keep the multi-pass schedule: the launch's fixed costs (team formation, pipeline fill, the last
+        // transforms of uneven teams) and an intermediate that still fits the Infinity Cache favour it.  Measured crossover
+        // (tools/team_sweep.py with SWEEP_BATCH): between 0.5 and 1 GiB of data per execute (2^20 fp32: +4 % at 64, +12 % at
+        // 128 transforms; 2^18: -3 % at 256, +14 % at 512; fp64 2^18: +5 % at 128, +16 % at 256) -> 1 GiB, and 8 per team
+        d.min_batch = mode == 1 ? (int)std::max<long long>(8ll * d.n_teams, (1ll << 30) / ((long long)SZ << log2n)) : d.n_teams;
         if (const char* e = getenv("FFT_HIP_TEAM_MIN_BATCH")) d.min_batch = atoi(e);
         (void)batch;
         d.ok = true;

@@ -109,10 +109,9 @@ struct HipRT {
         return true;
     }
     // sizes where the team kernel measured faster than the multi-pass schedule (tools/team_sweep.py at 4 GiB
-    // per execute): fp32 2^17..2^20 (+15, +24, +24, +15..19 %), fp64 2^15..2^19 (+28, +25, +35, +25, +16 %); fp32 2^16 (-4 %)
-    // stays multi-pass
+    // per execute): fp32 2^16..2^20 (+14, +15, +24, +24, +15..19 %), fp64 2^15..2^19 (+28, +25, +35, +25, +16 %)
     bool team_default_on(int elem_bytes, int log2n) {
-        return elem_bytes == 8 ? (log2n >= 17 && log2n <= 20) : (log2n >= 15 && log2n <= 19);
+        return elem_bytes == 8 ? (log2n >= 16 && log2n <= 20) : (log2n >= 15 && log2n <= 19);
     }
     // the column step on 128-byte row segments (fft_team.h ASPLIT), instantiated for fp32 n = 2^20 where the plain
     // tiles have 64-byte ones.  Measured 125 vs 137 Gpoint/s (the joined halves concentrate twiddles and hand-over in

@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.join(%r, "fft-implementation-in-c_amd"))
 import fftlib
 log2n, dtype = int(sys.argv[1]), (np.complex64 if sys.argv[2] == "f32" else np.complex128)
 n = 1 << log2n
-batch = max(1, (4 << 30) // (n * np.dtype(dtype).itemsize))
+batch = int(os.environ.get("SWEEP_BATCH", "0")) or max(1, (4 << 30) // (n * np.dtype(dtype).itemsize))
 fftlib.init()
 a = fftlib.DeviceBuffer(n * batch * np.dtype(dtype).itemsize)
 b = fftlib.DeviceBuffer(n * batch * np.dtype(dtype).itemsize)
@@ -41,7 +41,7 @@ def main():
     sz = 8 if dtype == "f32" else 16
     for log2n in sizes:
         n = 1 << log2n
-        batch = max(1, (4 << 30) // (n * sz))
+        batch = int(os.environ.get("SWEEP_BATCH", "0")) or max(1, (4 << 30) // (n * sz))
         row = []
         ms, info = run(log2n, dtype, {"FFT_HIP_TEAM": "0"})
         row.append("multi-pass %.1f" % (n * batch / ms / 1e6))
