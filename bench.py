@@ -347,9 +347,12 @@ def main():
         n_groups, units_per_launch = 1, batch
         team_ms = per_pass[0]["avg_launch_ms"] if per_pass else ev_ms_per_step
         achieved = bytes_alg_per_step_gpu / (team_ms * 1e-3) / 1e9
-        kernel_desc = ("team_defer_kernel (csrc/fft_team_defer.h): ONE launch per step transforms all %d transforms, a whole transform per XCD "
-                       "(256 workgroups = 8 teams of 32, %d tiles per workgroup and step); the %d multi-pass launches "
-                       "queued behind it as its fallback return at once" % (batch, info.team_tiles, launches))
+        tile_points = 8192 if dtype == "f32" else 4096  # one 64 KiB tile
+        team_cus = max(1, n // (info.team_tiles * tile_points))
+        kernel_desc = ("team kernel (csrc/fft_team_defer.h team_defer_kernel, or csrc/fft_team.h team_fft_kernel where the plain "
+                       "schedule measured faster): ONE launch per step transforms all %d transforms, a whole transform per team of "
+                       "%d CUs of one XCD (256 workgroups = %d teams, %d tiles per workgroup and step); the %d multi-pass launches "
+                       "queued behind it as its fallback return at once" % (batch, team_cus, 256 // team_cus, info.team_tiles, launches))
     else:
         kernel_desc = ("tile_fft_kernel: one launch per pass per group of %d transforms (%d launches per step); the "
                        "dominant unit of work is the launch SET that carries a group through all %d passes"
@@ -381,7 +384,7 @@ def main():
             "parallelism": "batch index sharded over %d GPU(s), one process per GPU, no collectives" % world,
             "algo": args.algo, "passes": info.n_passes, "factors": [v for v in info.factors if v],
             "chunk_batch": info.chunk_batch, "bluestein_m": info.bluestein_m,
-            "schedule": "team kernel: one HBM round trip, whole transform per XCD" if team else
+            "schedule": "team kernel: one HBM round trip, a whole transform per team of CUs of one XCD" if team else
                         ("multi-pass (team kernel fell back)" if team_status == 1 else "multi-pass"),
             "team_tiles": info.team_tiles, "team_status": team_status,
             "device": lib.fft_gpu_get_device_name().decode(),
