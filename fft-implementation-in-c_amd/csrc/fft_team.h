@@ -30,8 +30,9 @@
 //               stores the result transposed => natural order in HBM.
 //   * Same-XCD visibility needs no cache maintenance: a plain store is in the L2
 //     once vmcnt says so (the vector L1 is write-through), an sc1 load bypasses the
-//     reader's L1.  The team barrier is a line of 32 generation words, one per
-//     member, stored plain and polled with sc1 loads.  Every spin is bounded.
+//     reader's L1.  The team barrier is one arrival counter per team in that L2
+//     (no-return atomic add; polled by the first wave of a workgroup with scalar
+//     loads, the other waves wait at the workgroup barrier).  Every spin is bounded.
 //
 // HBM traffic per transform: n elements in, n elements out -- the algorithmic
 // minimum; the transposition traffic stays inside the XCD.
@@ -197,8 +198,9 @@ FFT_DEVICE void team_hand_over(unsigned char* sb, const cpx<T> (&y)[K], int n2, 
 }
 
 // ---------------------------------------------------------------------------
-// The kernel.  Per transform a workgroup signals NT + 1 "arrivals" on its team's flag line (generation numbers
-// count up across transforms); a wait is a poll of the whole line by every wave that needs it:
+// The kernel.  Per transform a workgroup signals NT + 1 "arrivals" (generation numbers count up across transforms) on
+// its team's counter (NT == 4: every member waits for everybody's arrival g before its own arrival g + 1, so
+// count >= TS * g says "everybody has arrived at g") or flag line (NT < 4, tests: one generation word per member):
 //   a0        my hand-over of phases 0 and 1 (written while the column tiles were transformed) is in L2
 //   a1        my row tile of phase 0 has landed in LDS
 //   a(ph+2)   end of row phase ph < NT-1: my row tile of phase ph+1 has landed, my hand-over of phase ph+2 is in L2
