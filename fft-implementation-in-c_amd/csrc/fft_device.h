@@ -65,6 +65,7 @@ inline T shfl_xor_any(T v, int mask) {
 #define FFT_L2_COUNT_ADD(p) ((void)__atomic_fetch_add((p), 1u, __ATOMIC_SEQ_CST))
 #define FFT_L2_COUNT_POLL(p) __atomic_load_n((p), __ATOMIC_SEQ_CST)
 #define FFT_LDS_FRESH() __atomic_thread_fence(__ATOMIC_SEQ_CST)
+#define FFT_SCHED_BARRIER() ((void)0)
 #define FFT_WAIT_VM0() __atomic_thread_fence(__ATOMIC_SEQ_CST)
 #define FFT_SLEEP() sched_yield()
 #define FFT_CLOCK() emu::clock_ticks()
@@ -134,6 +135,7 @@ __device__ __forceinline__ unsigned fft_scalar_load_glc(const unsigned* p) {
 // the next read of a (non-volatile) LDS word is a real ds_read: volatile accesses through a pointer whose address
 // space the compiler has to infer come out as FLAT loads, which wait on vmcnt as well
 #define FFT_LDS_FRESH() asm volatile("" ::: "memory")
+#define FFT_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)  // the instruction scheduler moves nothing across this point
 #define FFT_WAIT_VM0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #define FFT_SLEEP() __builtin_amdgcn_s_sleep(2)
 #define FFT_CLOCK() ((long long)wall_clock64())

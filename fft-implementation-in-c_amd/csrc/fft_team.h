@@ -152,6 +152,30 @@ FFT_DEVICE void team_all_stages(cpx<T> (&x)[1][E][1], const unsigned char* land,
     hook(total - 1, total);  // the last slot: after the final stage (which has no exchange, hence no mid-stage barrier)
 }
 
+// x[e] *= W_n^(m_start + e * m_step) from the two-level LDS table (t0: low t0_bits of the exponent, t1: the rest).
+// The table reads of FOUR slots are issued together and then consumed: left to itself the compiler emits read, read,
+// wait, multiply per slot, i.e. sixteen LDS round trips in a row on the critical path of every column tile.
+template <typename T, int E>
+FFT_DEVICE void team_interpass_twiddle(cpx<T> (&x)[1][E][1], const cpx<T>* t0, const cpx<T>* t1, int t0_bits, unsigned m_start,
+                                       unsigned m_step) {
+    constexpr int B = 4;
+    const unsigned m0 = (1u << t0_bits) - 1u;
+    FFT_UNROLL
+    for (int e0 = 0; e0 < E; e0 += B) {
+        cpx<T> a[B], b[B];
+        FFT_UNROLL
+        for (int k = 0; k < B; k++) {
+            const unsigned m = m_start + (unsigned)(e0 + k) * m_step;
+            a[k] = t0[m & m0];
+            b[k] = t1[m >> t0_bits];
+        }
+        FFT_SCHED_BARRIER();
+        FFT_UNROLL
+        for (int k = 0; k < B; k++) x[0][e0 + k][0] = cmul(x[0][e0 + k][0], cmul(a[k], b[k]));
+        FFT_SCHED_BARRIER();
+    }
+}
+
 // Two lanes (l, l ^ mask) hold the same slots of two ADJACENT rows (even lane: row i, odd lane: row i + 1).  For the
 // slot pair (s0, s1) each lane ends up with BOTH rows of ONE slot -- the even lane of s0, the odd lane of s1 -- i.e.
 // 16 contiguous bytes of an image whose rows are adjacent in memory: half as many, twice as wide stores.
@@ -509,15 +533,8 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
                 dma_column_tile(inb, t + 1, 0, NCH);
             }
             if (!(p.ablate & 1)) {  // W_n^(k1 n2), two-level LDS table
-                const cpx<T>* t0 = tab + p.o_t0;
-                const cpx<T>* t1 = tab + p.o_t1;
-                const unsigned m0 = (1u << p.t0_bits) - 1u;
-                const unsigned c0 = (unsigned)(column_block(t) << log2CA);
-                FFT_UNROLL
-                for (int e = 0; e < E; e++) {
-                    const unsigned m = (unsigned)(rA + (e << log2TPCA)) * (c0 + jA);
-                    x[0][e][0] = cmul(x[0][e][0], cmul(t0[m & m0], t1[m >> p.t0_bits]));
-                }
+                const unsigned n2 = (unsigned)(column_block(t) << log2CA) + (unsigned)jA;
+                team_interpass_twiddle<T, E>(x, tab + p.o_t0, tab + p.o_t1, p.t0_bits, (unsigned)rA * n2, n2 << log2TPCA);
             }
             // windows S0, S1 were last read by the previous transform's final phases: everybody is past them?
             if (t == 0 && g0 > 1) wait_all(g0 - 1);

@@ -262,15 +262,8 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
                 }
             }, p.inverse != 0);
             {
-                const cpx<T>* t0 = tab + p.o_t0;
-                const cpx<T>* t1 = tab + p.o_t1;
-                const unsigned m0 = (1u << p.t0_bits) - 1u;
-                const unsigned c0 = (unsigned)(column_block(t) << log2CA);
-                FFT_UNROLL
-                for (int e = 0; e < E; e++) {
-                    const unsigned m = (unsigned)(rA + (e << log2TPCA)) * (c0 + jA);
-                    x[0][e][0] = cmul(x[0][e][0], cmul(t0[m & m0], t1[m >> p.t0_bits]));
-                }
+                const unsigned n2 = (unsigned)(column_block(t) << log2CA) + (unsigned)jA;
+                team_interpass_twiddle<T, E>(x, tab + p.o_t0, tab + p.o_t1, p.t0_bits, (unsigned)rA * n2, n2 << log2TPCA);
             }
             if (t == 0 && it > 0) wait_all(G);  // S0 / S1 were last read by row tiles 2 / 1 of it-1 (X4 covers both)
             FFT_UNROLL
