@@ -183,6 +183,38 @@ FFT_DEVICE void stockham_stage_rw(cpx<T> (&x)[H][E][V], const unsigned char* sme
         }
     }
 
+    // Output twiddles W^(tq * k), k = 1 .. R-1, of the thread's G butterflies: NTW table reads.  Left to itself the
+    // compiler emits read, wait, multiply per twiddle -- NTW LDS round trips in a row behind the butterflies.  Here the
+    // reads go out in batches of TB: the first batch BEFORE the butterflies (it lands under their arithmetic), batch b + 1
+    // before the multiplies of batch b.  (Two-level tables: both factors are read, the product is formed at use.)
+    // Only where the register budget has room for it (SWZ bit 2: the team kernels, two waves per SIMD).
+    constexpr bool PIPE_TW = (SWZ & 4) != 0;
+    constexpr int NTW = PIPE_TW ? G * (R - 1) : 0;
+    constexpr int TB = 4;
+    const bool tw_one_level = tw.sa_bits >= tw.log2L;  // wave-uniform
+    cpx<T> wa[NTW > 0 ? NTW : 1], wb[NTW > 0 ? NTW : 1];
+    auto tw_load_batch = [&](int b) __attribute__((always_inline)) {
+        FFT_UNROLL
+        for (int f = b * TB; f < (b + 1) * TB; f++) {
+            if (f < NTW) {
+                const int m = f / (R - 1), k = f % (R - 1) + 1;
+                const int u = r + (m << log2TPC);
+                const int q = u & Li_mask;
+                const int mm = ((q << log2P) * k) & ((1 << tw.log2L) - 1);
+                if (tw_one_level) {
+                    wa[f] = tw.sa[mm];
+                } else {
+                    wa[f] = tw.sa[mm & ((1 << tw.sa_bits) - 1)];
+                    wb[f] = tw.sb[mm >> tw.sa_bits];
+                }
+            }
+        }
+    };
+    if (PIPE_TW && !last) {
+        tw_load_batch(0);
+        FFT_SCHED_BARRIER();
+    }
+
     FFT_UNROLL
     for (int h = 0; h < H; h++) {
         FFT_UNROLL
@@ -200,20 +232,40 @@ FFT_DEVICE void stockham_stage_rw(cpx<T> (&x)[H][E][V], const unsigned char* sme
     }
 
     if (!last) {
-        FFT_UNROLL
-        for (int m = 0; m < G; m++) {
-            const int u = r + (m << log2TPC);
-            const int q = u & Li_mask;
-            const int tq = q << log2P;
+        if (!PIPE_TW) {
             FFT_UNROLL
-            for (int k = 1; k < R; k++) {
-                const cpx<T> w = tw.get(tq * k);  // one lookup serves all groups and both columns
+            for (int m = 0; m < G; m++) {
+                const int u = r + (m << log2TPC);
+                const int q = u & Li_mask;
+                const int tq = q << log2P;
                 FFT_UNROLL
-                for (int h = 0; h < H; h++) {
+                for (int k = 1; k < R; k++) {
+                    const cpx<T> w = tw.get(tq * k);  // one lookup serves all groups and both columns
                     FFT_UNROLL
-                    for (int vv = 0; vv < V; vv++) x[h][m + G * k][vv] = cmul(x[h][m + G * k][vv], w);
+                    for (int h = 0; h < H; h++) {
+                        FFT_UNROLL
+                        for (int vv = 0; vv < V; vv++) x[h][m + G * k][vv] = cmul(x[h][m + G * k][vv], w);
+                    }
                 }
             }
+        }
+        FFT_UNROLL
+        for (int b = 0; b * TB < NTW; b++) {
+            if ((b + 1) * TB < NTW) tw_load_batch(b + 1);
+            FFT_SCHED_BARRIER();
+            FFT_UNROLL
+            for (int f = b * TB; f < (b + 1) * TB; f++) {
+                if (f < NTW) {
+                    const int m = f / (R - 1), k = f % (R - 1) + 1;
+                    const cpx<T> w = tw_one_level ? wa[f] : cmul(wa[f], wb[f]);  // one lookup serves all groups and both columns
+                    FFT_UNROLL
+                    for (int h = 0; h < H; h++) {
+                        FFT_UNROLL
+                        for (int vv = 0; vv < V; vv++) x[h][m + G * k][vv] = cmul(x[h][m + G * k][vv], w);
+                    }
+                }
+            }
+            FFT_SCHED_BARRIER();
         }
         if (!first) {
             FFT_SYNC_LDS();  // everyone has finished reading the previous exchange

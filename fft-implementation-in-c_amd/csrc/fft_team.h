@@ -135,11 +135,11 @@ FFT_DEVICE void team_all_stages(cpx<T> (&x)[1][E][1], const unsigned char* land,
     for (int s = 0; s < n_full; s++) {
         StageHookAt<Hook> h{hook, s, total};
         if (swz && s == n_full - 1)
-            stockham_stage_rw<T, E, E, 1, 1, 2>(x, s == 0 ? land : work, work, 0, tw, r, j, log2J, log2TPC, log2Lprev, log2P,
+            stockham_stage_rw<T, E, E, 1, 1, 2 | 4>(x, s == 0 ? land : work, work, 0, tw, r, j, log2J, log2TPC, log2Lprev, log2P,
                                                 false, s == total - 1, h, s == 0 && swap_in);
         else
-            stockham_stage_rw<T, E, E, 1, 1>(x, s == 0 ? land : work, work, 0, tw, r, j, log2J, log2TPC, log2Lprev, log2P, false,
-                                             s == total - 1, h, s == 0 && swap_in);
+            stockham_stage_rw<T, E, E, 1, 1, 4>(x, s == 0 ? land : work, work, 0, tw, r, j, log2J, log2TPC, log2Lprev, log2P, false,
+                                                s == total - 1, h, s == 0 && swap_in);
     }
     // the remaining stage is always the last one: no exchange, no hook
     if (rem == 1) stockham_stage_rw<T, E, 2, 1, 1>(x, work, work, 0, tw, r, j, log2J, log2TPC, log2Lprev, log2P, false, true, StageNoHook());
