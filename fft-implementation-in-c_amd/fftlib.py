@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libfft_mi355x.so")
+LIB_PATH = os.environ.get("FFT_LIB_PATH") or os.path.join(HERE, "libfft_mi355x.so")  # FFT_LIB_PATH: tools A/B-ing two builds
 
 FFT_FORWARD = -1
 FFT_INVERSE = 1
