@@ -121,12 +121,11 @@ struct HipRT {
         return on && elem_bytes == 8 && log2n == 20;
     }
     // team_defer_kernel (fft_team_defer.h: the last row phase fills the turn of the next transform) instead of
-    // team_fft_kernel: +3..6 % at fp32 n = 2^20, 2^19 and +3..12 % for fp64; the small fp32 teams (2^17, 2^18: 4 and 8
-    // CUs wait little at the turn) are 2-3 % faster without the third window.  FFT_HIP_TEAM_DEFER=0 / 1 forces either.
-    bool team_defer(int elem_bytes, int log2n) {
-        static const int forced = getenv("FFT_HIP_TEAM_DEFER") ? atoi(getenv("FFT_HIP_TEAM_DEFER")) : -1;
-        if (forced >= 0) return forced != 0;
-        return elem_bytes == 16 || log2n >= 19;
+    // team_fft_kernel: +2..8 % at every built size (profiles/r1e_team_variant_sweep.txt).  FFT_HIP_TEAM_DEFER=0 runs the
+    // plain kernel.
+    bool team_defer(int /*elem_bytes*/, int /*log2n*/) {
+        static const int on = getenv("FFT_HIP_TEAM_DEFER") ? atoi(getenv("FFT_HIP_TEAM_DEFER")) : 1;
+        return on != 0;
     }
     long long team_timeout_ticks() { return 20000000ll; }  // 0.2 s of the 100 MHz wall clock
     template <class K, class... A>
