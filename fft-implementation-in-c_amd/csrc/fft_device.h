@@ -47,7 +47,7 @@ inline T shfl_xor_any(T v, int mask) {
 }
 }  // namespace emu
 #define FFT_SHFL_XOR(v, mask) emu::shfl_xor_any(v, mask)
-#define FFT_XOR_EXCHANGE(v, mask) emu::shfl_xor_any(v, mask)
+#define FFT_XOR_EXCHANGE(v, mask, upper) emu::shfl_xor_any(v, mask)
 #define FFT_OPAQUE(v) (void)(v)
 #define FFT_LAUNCH_BOUNDS(n)
 #define FFT_LAUNCH_BOUNDS2(n, w)
@@ -98,16 +98,27 @@ inline T shfl_xor_any(T v, int mask) {
 // stores are issued keeps the store latency out of the next iteration's critical path.
 #define FFT_WAIT_LOADED(v) asm volatile("" ::"v"(v))
 #define FFT_SHFL_XOR(v, mask) __shfl_xor(v, mask, 64)
-// lane ^ mask exchange of one float.  Masks 1 and 8 stay inside a row of 16 lanes and are DPP moves (quad_perm [1,0,3,2],
-// row_ror:8): VALU-rate, no trip through the LDS crossbar and no lgkmcnt wait like the ds_bpermute behind __shfl_xor.
-#define FFT_XOR_EXCHANGE(v, mask) fft_xor_exchange((v), (mask))
-__device__ __forceinline__ float fft_xor_exchange(float v, int mask) {
+// lane ^ mask exchange of one float; `upper` = this lane has the mask bit set.  Masks 1 and 8 stay inside a row of 16 lanes
+// and are DPP moves (quad_perm [1,0,3,2], row_ror:8); 16 and 32 are the gfx950 row / half swaps (v_permlane16_swap,
+// v_permlane32_swap: the odd rows / upper half of the first operand trade places with the even rows / lower half of the
+// second -- with the same value in both, the lane finds its partner's value in the first result if `upper`, else in the
+// second).  All VALU-rate: no trip through the LDS crossbar and no lgkmcnt wait like the ds_bpermute behind __shfl_xor.
+#define FFT_XOR_EXCHANGE(v, mask, upper) fft_xor_exchange((v), (mask), (upper))
+__device__ __forceinline__ float fft_xor_exchange(float v, int mask, bool upper) {
     const int iv = __builtin_bit_cast(int, v);
     if (mask == 1) return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, iv, 0xB1, 0xF, 0xF, true));
     if (mask == 8) return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, iv, 0x128, 0xF, 0xF, true));
+    if (mask == 16) {
+        const auto r = __builtin_amdgcn_permlane16_swap((unsigned)iv, (unsigned)iv, false, false);
+        return __builtin_bit_cast(float, upper ? r[0] : r[1]);
+    }
+    if (mask == 32) {
+        const auto r = __builtin_amdgcn_permlane32_swap((unsigned)iv, (unsigned)iv, false, false);
+        return __builtin_bit_cast(float, upper ? r[0] : r[1]);
+    }
     return __shfl_xor(v, mask, 64);
 }
-__device__ __forceinline__ double fft_xor_exchange(double v, int mask) { return __shfl_xor(v, mask, 64); }
+__device__ __forceinline__ double fft_xor_exchange(double v, int mask, bool) { return __shfl_xor(v, mask, 64); }
 // Hide a loop-invariant value from the optimizer: without this, LICM hoists every per-stage LDS address and
 // twiddle index out of the persistent tile loop and keeps hundreds of them live in VGPRs across it.
 #ifdef FFT_NO_OPAQUE

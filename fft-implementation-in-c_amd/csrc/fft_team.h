@@ -186,8 +186,8 @@ FFT_DEVICE void pair_rows(cpx<T> own_s0, cpx<T> own_s1, bool odd, int mask, vec1
     // the optimizer from promoting the array to registers
     const T send_re = odd ? own_s0.re : own_s1.re;
     const T send_im = odd ? own_s0.im : own_s1.im;
-    const T recv_re = FFT_XOR_EXCHANGE(send_re, mask);
-    const T recv_im = FFT_XOR_EXCHANGE(send_im, mask);
+    const T recv_re = FFT_XOR_EXCHANGE(send_re, mask, odd);  // odd <=> this lane has the mask bit set
+    const T recv_im = FFT_XOR_EXCHANGE(send_im, mask, odd);
     out.c[0].re = odd ? recv_re : own_s0.re;  // row i
     out.c[0].im = odd ? recv_im : own_s0.im;
     out.c[1].re = odd ? own_s1.re : recv_re;  // row i + 1
