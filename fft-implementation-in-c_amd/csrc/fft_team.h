@@ -40,6 +40,11 @@
 
 #include "fft_kernels.h"
 
+// chunks of a tile's landing DMA that go out from the first stage slot (the rest from the second)
+#ifndef FFT_TEAM_DMA_FIRST
+#define FFT_TEAM_DMA_FIRST(nch) ((nch) / 2)
+#endif
+
 namespace fftk {
 
 // control block (32-bit words), zeroed before every launch
@@ -468,8 +473,8 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
                 const bool more = (t + 1 < NT);
                 team_all_stages<T, E>(x, land, work, twA, rA2, jA2, log2CA2, log2TPCA2, log2H1, [&](int s, int total) {
                     if (more) {
-                        if (s == 0) dma_half_tile(inb, t + 1, 0, total >= 2 ? NCH / 2 : NCH);
-                        if (s == 1) dma_half_tile(inb, t + 1, NCH / 2, NCH);
+                        if (s == 0) dma_half_tile(inb, t + 1, 0, total >= 2 ? FFT_TEAM_DMA_FIRST(NCH) : NCH);
+                        if (s == 1) dma_half_tile(inb, t + 1, FFT_TEAM_DMA_FIRST(NCH), NCH);
                     }
                 }, p.inverse != 0);
                 if ((t & 1) == 0) {
@@ -524,8 +529,8 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
                 team_all_stages<T, E>(x, land, work, twA, rA, jA, log2CA, log2TPCA, log2L1, [&](int s, int total) {
                     // the next tile flies during the remaining stages; issued in two halves (a CU's memory queue is short)
                     if (more) {
-                        if (s == 0) dma_column_tile(inb, t + 1, 0, total >= 2 ? NCH / 2 : NCH);
-                        if (s == 1) dma_column_tile(inb, t + 1, NCH / 2, NCH);
+                        if (s == 0) dma_column_tile(inb, t + 1, 0, total >= 2 ? FFT_TEAM_DMA_FIRST(NCH) : NCH);
+                        if (s == 1) dma_column_tile(inb, t + 1, FFT_TEAM_DMA_FIRST(NCH), NCH);
                     }
                 }, p.inverse != 0);  // inverse = forward transform between two re<->im swaps: first one here
             } else if (more) {

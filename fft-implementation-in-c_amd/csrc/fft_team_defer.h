@@ -181,8 +181,8 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
         }
     };
     // chunks of a landing DMA issued from slot s of a tile with `total` slots: two halves from slots 0 and 1
-    auto slot_i0 = [&](int s) __attribute__((always_inline)) { return s == 0 ? 0 : NCH / 2; };
-    auto slot_i1 = [&](int s, int total) __attribute__((always_inline)) { return s == 0 ? (total >= 2 ? NCH / 2 : NCH) : NCH; };
+    auto slot_i0 = [&](int s) __attribute__((always_inline)) { return s == 0 ? 0 : FFT_TEAM_DMA_FIRST(NCH); };
+    auto slot_i1 = [&](int s, int total) __attribute__((always_inline)) { return s == 0 ? (total >= 2 ? FFT_TEAM_DMA_FIRST(NCH) : NCH) : NCH; };
     // hand over phase ph (2 or 3) from the kept registers into window `sb`, all four column tiles
     auto hand_over_kept = [&](unsigned char* sb, int ph, int rA, int jA) __attribute__((always_inline)) {
         const bool third = (ph == 3);
