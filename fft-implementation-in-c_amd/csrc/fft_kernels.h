@@ -190,7 +190,10 @@ FFT_DEVICE void stockham_stage_rw(cpx<T> (&x)[H][E][V], const unsigned char* sme
     // Only where the register budget has room for it (SWZ bit 2: the team kernels, two waves per SIMD).
     constexpr bool PIPE_TW = (SWZ & 4) != 0;
     constexpr int NTW = PIPE_TW ? G * (R - 1) : 0;
-    constexpr int TB = 4;
+#ifndef FFT_TW_BATCH
+#define FFT_TW_BATCH 4
+#endif
+    constexpr int TB = FFT_TW_BATCH;
     const bool tw_one_level = tw.sa_bits >= tw.log2L;  // wave-uniform
     cpx<T> wa[NTW > 0 ? NTW : 1], wb[NTW > 0 ? NTW : 1];
     auto tw_load_batch = [&](int b) __attribute__((always_inline)) {
