@@ -247,7 +247,11 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
         const int jA = tid & ((1 << log2CA) - 1), rA = tid >> log2CA;
 
         // ================= column step; under its last tile the deferred row tile (phase 3 of it-1) is fetched
+#ifdef FFT_TEAM_UNROLL_A
+        FFT_UNROLL
+#else
         FFT_NOUNROLL
+#endif
         for (int t = 0; t < NT; t++) {
             cpx<T> x[1][E][1];
             FFT_WAIT_VM0();
