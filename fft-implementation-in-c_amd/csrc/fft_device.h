@@ -54,6 +54,7 @@ inline T shfl_xor_any(T v, int mask) {
 #define FFT_RESTRICT
 #define FFT_UNROLL
 #define FFT_NOUNROLL
+#define FFT_UNROLL_N(n)
 // ---- team-kernel vocabulary (fft_team.h): the emulation runs the workgroups of a launch concurrently, a "XCD"
 // is blockIdx mod n_teams, every memory operation is sequentially consistent
 #include <sched.h>
@@ -131,6 +132,8 @@ __device__ __forceinline__ double fft_xor_exchange(double v, int mask, bool) { r
 #define FFT_RESTRICT __restrict__
 #define FFT_UNROLL _Pragma("unroll")
 #define FFT_NOUNROLL _Pragma("nounroll")
+#define FFT_PRAGMA_(x) _Pragma(#x)
+#define FFT_UNROLL_N(n) FFT_PRAGMA_(unroll n)  // n: an integral constant expression (1 = keep the loop)
 // ---- team-kernel vocabulary (fft_team.h)
 // The XCD this wave runs on (HW_REG_XCC_ID, bits 3:0).  Workgroups that read the same id share one L2.
 #define FFT_XCC_ID(nteams) ((unsigned)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15u)
