@@ -62,6 +62,15 @@ inline T shfl_xor_any(T v, int mask) {
 #define FFT_ATOMIC_ADD_AGENT(p, v) __atomic_fetch_add((p), (v), __ATOMIC_SEQ_CST)
 #define FFT_ATOMIC_LOAD_AGENT(p) __atomic_load_n((p), __ATOMIC_SEQ_CST)
 #define FFT_ATOMIC_STORE_AGENT(p, v) __atomic_store_n((p), (v), __ATOMIC_SEQ_CST)
+namespace emu {
+inline unsigned cas_u32(unsigned* p, unsigned expected, unsigned desired) {  // returns the value found
+    __atomic_compare_exchange_n(p, &expected, desired, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST);
+    return expected;
+}
+void test_delay();  // test hook: one chosen workgroup sleeps before it registers (FFT_EMU_LATE_BLOCK / _MS)
+}  // namespace emu
+#define FFT_ATOMIC_CAS_AGENT(p, expected, desired) emu::cas_u32((p), (expected), (desired))
+#define FFT_TEST_DELAY() emu::test_delay()
 #define FFT_L2_FLAG_STORE(p, v) __atomic_store_n((p), (v), __ATOMIC_SEQ_CST)
 #define FFT_L2_FLAG_LOAD(p) __atomic_load_n((p), __ATOMIC_SEQ_CST)
 #define FFT_L2_COUNT_ADD(p) ((void)__atomic_fetch_add((p), 1u, __ATOMIC_SEQ_CST))
@@ -141,6 +150,12 @@ __device__ __forceinline__ double fft_xor_exchange(double v, int mask, bool) { r
 #define FFT_ATOMIC_ADD_AGENT(p, v) __hip_atomic_fetch_add((p), (v), __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT)
 #define FFT_ATOMIC_LOAD_AGENT(p) __hip_atomic_load((p), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)
 #define FFT_ATOMIC_STORE_AGENT(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT)
+__device__ __forceinline__ unsigned fft_cas_agent(unsigned* p, unsigned expected, unsigned desired) {  // returns the value found
+    __hip_atomic_compare_exchange_strong(p, &expected, desired, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+    return expected;
+}
+#define FFT_ATOMIC_CAS_AGENT(p, expected, desired) fft_cas_agent((p), (expected), (desired))
+#define FFT_TEST_DELAY() ((void)0)
 // Same-XCD signalling through the XCD's own L2: a PLAIN dword store stays in L2 (write-through L1), an sc1 load
 // bypasses the reader's L1 and is served by that L2.  Valid ONLY between workgroups that read the same XCC id.
 // (hand-written: a volatile C store comes out as flat_store_dword sc0 sc1, i.e. written through to memory)
@@ -215,6 +230,19 @@ __device__ __forceinline__ void fft_dma16(const void* gsrc, unsigned lane_lds_ad
     (void)lane_lds_addr;
 #endif
 }
+#endif
+
+// Experiment / ablation switches (environment variables read by the planner, ablation bits read by the kernels) exist
+// only in builds made with -DFFT_EXPERIMENTS (libfft_mi355x_exp.so: tools/, the variant tests).  In the shipped
+// library FFT_EXP_ENV() is a null constant and FFT_ABLATE() a zero constant, so every such branch folds away: the
+// product cannot be told to skip work, and reads no environment variable per execute.
+#if defined(FFT_EXPERIMENTS)
+#include <stdlib.h>
+#define FFT_EXP_ENV(name) getenv(name)
+#define FFT_ABLATE(bits) (bits)
+#else
+#define FFT_EXP_ENV(name) ((const char*)0)
+#define FFT_ABLATE(bits) 0
 #endif
 
 namespace fftk {

@@ -14,7 +14,9 @@
 //   void  mark(int pass_index);   // profiling hook, called after each pass launch (no-op unless enabled)
 //   void  memset_async(void*, int, size_t);
 //   bool  team_geometry(int& log2seats, int& n_xcc, int& nthreads);   // false: no team kernel on this device
-//   long long team_timeout_ticks();
+//   long long team_timeout_ticks();        // bound of a team wait (deadlock breaker)
+//   long long team_form_timeout_ticks();   // bound of team formation (shared device -> multi-pass fallback)
+//   EnginePolicy policy;                   // the few production knobs, read once when the runtime is set up
 //   template <class K, class... A> void launch_coresident(K kernel, long long grid, int block, size_t smem, A... args);
 //
 // Scheme (reference optimizations/parallel_fft.c:213-272 is the
@@ -43,6 +45,13 @@
 namespace ffteng {
 
 using fftk::cpx;
+
+// Production policy knobs (everything else that steers the planner is an experiment switch: FFT_EXP_ENV, fft_device.h).
+struct EnginePolicy {
+    int team_mode = 1;         // FFT_HIP_TEAM: 0 never the team kernel, 1 where it measured faster, 2 every built size
+    int team_min_batch = 0;    // FFT_HIP_TEAM_MIN_BATCH: > 0 overrides the measured batch crossover
+    long long chunk_mb = 0;    // FFT_HIP_CHUNK_MB: > 0 overrides the multi-pass launch-group size
+};
 
 enum Algo { ALGO_AUTO = 0, ALGO_RADIX2 = 1, ALGO_RADIX4 = 2, ALGO_SPLIT_RADIX = 3, ALGO_RADIX2_GLOBAL = 4, ALGO_BLUESTEIN = 5, ALGO_RADIX2_SHFL = 6 };
 
@@ -76,7 +85,7 @@ inline int tile_E(long long L, int kind) {  // kind: 0 single-pass rows, 1 colum
     if (!init) {
         init = true;
         pref[0] = 4; pref[1] = 8; pref[2] = 8;  // measured: rows-in/rows-out +8 % with 4 elements per thread (16 waves per CU); the multi-pass kernels lose 15-20 %
-        if (const char* e = getenv("FFT_HIP_E")) sscanf(e, "%d,%d,%d", &pref[0], &pref[1], &pref[2]);
+        if (const char* e = FFT_EXP_ENV("FFT_HIP_E")) sscanf(e, "%d,%d,%d", &pref[0], &pref[1], &pref[2]);
     }
     int e = (pref[kind] == 4) ? 4 : 8;
     while (e > L) e >>= 1;
@@ -123,6 +132,7 @@ struct TeamDesc {
     unsigned char* scratch = nullptr;
     size_t scratch_bytes = 0;
     unsigned* ctl = nullptr;
+    unsigned* sticky = nullptr;  // the allocation: [ TEAM_STICKY_WORDS | control block ]; ctl points behind the sticky words
     long long* trace = nullptr;  // profiling only (fft_gpu_plan_team_trace_hip); caller-owned device memory
     int trace_events = 0;
 };
@@ -149,6 +159,7 @@ class Pow2Plan {
     int team_pending = 0;        // team launches since the host last read the status word
     int team_fallbacks = 0;      // consecutive executes that ended in the two-pass fallback
     int team_last_status = -1;   // what the host last read from the status word (-1: never launched)
+    bool team_force_fallback = false;  // test hook: the team kernel pretends its placement check failed
     bool ok = false;
 
     ~Pow2Plan() { destroy(); }
@@ -161,7 +172,7 @@ class Pow2Plan {
         if (scratch) rt->dfree(scratch);
         if (team.tables) rt->dfree(team.tables);
         if (team.scratch) rt->dfree(team.scratch);
-        if (team.ctl) rt->dfree(team.ctl);
+        if (team.sticky) rt->dfree(team.sticky);
         team = TeamDesc<T>();
         tw_half = nullptr;
         scratch = nullptr;
@@ -171,8 +182,7 @@ class Pow2Plan {
     void build_team(int batch) {
         // FFT_HIP_TEAM: 0 never; 1 (default) where it measured faster than the multi-pass schedule on MI355X
         // (RT::team_default_on); 2 every size the kernel is built for (fft_team_list.h)
-        int mode = 1;
-        if (const char* e = getenv("FFT_HIP_TEAM")) mode = atoi(e);
+        const int mode = rt->policy.team_mode;
         if (mode <= 0) return;
         TeamDesc<T> d;
         if (!rt->team_geometry(d.log2seats, d.n_xcc, d.nthreads)) return;
@@ -185,7 +195,7 @@ class Pow2Plan {
         // for NT = 4 on a whole XCD does not fit the team's registers; NT = 2 / 1 on a whole XCD exist in the kernel
         // (and are emulated) but lose to the multi-pass schedule.
         int log2NT = 2;
-        if (const char* e = getenv("FFT_HIP_TEAM_TILES")) log2NT = ilog2(atoi(e));  // tests (emulation): 1 or 2 tiles
+        if (const char* e = FFT_EXP_ENV("FFT_HIP_TEAM_TILES")) log2NT = ilog2(atoi(e));  // tests (emulation): 1 or 2 tiles
         d.log2TS = log2n - log2NT - log2TE;
         if (d.log2TS > d.log2seats) return;
         if (d.log2TS < 1) return;  // a "team" of one CU exchanges nothing: single-CU sizes belong to the multi-pass plan
@@ -193,7 +203,7 @@ class Pow2Plan {
         d.n_teams = d.n_xcc << (d.log2seats - d.log2TS);
         if (mode == 1 && !rt->team_default_on(SZ, log2n)) return;
         d.log2L1 = log2n / 2;
-        if (const char* e = getenv("FFT_HIP_TEAM_L1")) d.log2L1 = atoi(e);  // experiments / tests: force the split
+        if (const char* e = FFT_EXP_ENV("FFT_HIP_TEAM_L1")) d.log2L1 = atoi(e);  // experiments / tests: force the split
         d.log2L2 = log2n - d.log2L1;
         d.log2CA = log2TE - d.log2L1;
         d.log2CB = log2TE - d.log2L2;
@@ -241,18 +251,21 @@ class Pow2Plan {
         d.scratch_bytes = ((size_t)SZ << (log2TE + d.log2TS)) * (d.defer ? 3 : 2) * (size_t)d.n_teams;  // 2 (3) windows of TS tiles per team
         d.tables = (cpx<T>*)rt->dmalloc(blob.size() * SZ);
         d.scratch = (unsigned char*)rt->dmalloc(d.scratch_bytes);
-        d.ctl = (unsigned*)rt->dmalloc(fftk::TEAM_CTL_WORDS * sizeof(unsigned));
-        if (!d.tables || !d.scratch || !d.ctl) {
-            rt->dfree(d.tables); rt->dfree(d.scratch); rt->dfree(d.ctl);
+        // [ sticky words | control block ]: only the control block is zeroed per launch
+        d.sticky = (unsigned*)rt->dmalloc((fftk::TEAM_STICKY_WORDS + fftk::TEAM_CTL_WORDS) * sizeof(unsigned));
+        d.ctl = d.sticky ? d.sticky + fftk::TEAM_STICKY_WORDS : nullptr;
+        if (!d.tables || !d.scratch || !d.sticky) {
+            rt->dfree(d.tables); rt->dfree(d.scratch); rt->dfree(d.sticky);
             return;
         }
+        rt->memset_async(d.sticky, 0, fftk::TEAM_STICKY_WORDS * sizeof(unsigned));
         rt->h2d(d.tables, blob.data(), blob.size() * SZ);
         // Small executes keep the multi-pass schedule: the launch's fixed costs (team formation, pipeline fill, the last
         // transforms of uneven teams) and an intermediate that still fits the Infinity Cache favour it.  Measured crossover
         // (tools/team_sweep.py with SWEEP_BATCH): between 0.5 and 1 GiB of data per execute (2^20 fp32: +4 % at 64, +12 % at
         // 128 transforms; 2^18: -3 % at 256, +14 % at 512; fp64 2^18: +5 % at 128, +16 % at 256) -> 1 GiB, and 8 per team
         d.min_batch = mode == 1 ? (int)std::max<long long>(8ll * d.n_teams, (1ll << 30) / ((long long)SZ << log2n)) : d.n_teams;
-        if (const char* e = getenv("FFT_HIP_TEAM_MIN_BATCH")) d.min_batch = atoi(e);
+        if (rt->policy.team_min_batch > 0) d.min_batch = rt->policy.team_min_batch;
         (void)batch;
         d.ok = true;
         team = d;
@@ -320,23 +333,25 @@ class Pow2Plan {
         tp.o_sb1 = team.o_sb1; tp.o_sa2 = team.o_sa2; tp.o_sb2 = team.o_sb2; tp.o_t0 = team.o_t0; tp.o_t1 = team.o_t1;
         tp.sa1_bits = team.sa1_bits; tp.sa2_bits = team.sa2_bits; tp.t0_bits = team.t0_bits;
         tp.timeout_ticks = rt->team_timeout_ticks();
-        static const int ablate = getenv("FFT_HIP_TEAM_ABLATE") ? atoi(getenv("FFT_HIP_TEAM_ABLATE")) : 0;  // profiling only
+        tp.form_timeout_ticks = rt->team_form_timeout_ticks();
+        tp.sticky = team.sticky;
+        static const int ablate = FFT_EXP_ENV("FFT_HIP_TEAM_ABLATE") ? atoi(FFT_EXP_ENV("FFT_HIP_TEAM_ABLATE")) : 0;  // profiling only
         tp.ablate = ablate;
-        static const int dma_split = getenv("FFT_HIP_TEAM_DMA_SPLIT") ? atoi(getenv("FFT_HIP_TEAM_DMA_SPLIT")) : 4;
+        static const int dma_split = FFT_EXP_ENV("FFT_HIP_TEAM_DMA_SPLIT") ? atoi(FFT_EXP_ENV("FFT_HIP_TEAM_DMA_SPLIT")) : 4;
         tp.dma_split = dma_split;
-        static const int dma_split2 = getenv("FFT_HIP_TEAM_DMA_SPLIT2") ? atoi(getenv("FFT_HIP_TEAM_DMA_SPLIT2")) : 8;
+        static const int dma_split2 = FFT_EXP_ENV("FFT_HIP_TEAM_DMA_SPLIT2") ? atoi(FFT_EXP_ENV("FFT_HIP_TEAM_DMA_SPLIT2")) : 8;
         tp.dma_split2 = dma_split2;
-        static const int seat_rot = getenv("FFT_HIP_TEAM_SEAT_ROT") ? atoi(getenv("FFT_HIP_TEAM_SEAT_ROT")) : 0;
+        static const int seat_rot = FFT_EXP_ENV("FFT_HIP_TEAM_SEAT_ROT") ? atoi(FFT_EXP_ENV("FFT_HIP_TEAM_SEAT_ROT")) : 0;
         tp.seat_rot = seat_rot;
-        static const int tile_rot = getenv("FFT_HIP_TEAM_TILE_ROT") ? atoi(getenv("FFT_HIP_TEAM_TILE_ROT")) : 4;
+        static const int tile_rot = FFT_EXP_ENV("FFT_HIP_TEAM_TILE_ROT") ? atoi(FFT_EXP_ENV("FFT_HIP_TEAM_TILE_ROT")) : 4;
         tp.tile_rot = tile_rot;
         // column-tile DMA with the non-temporal bit (read once: the first lines to leave the L2, which keeps more of the
         // hand-over windows there): +1..3 % at every size; nt result stores and nt window loads measured even or worse
-        static const int nt_mask = getenv("FFT_HIP_TEAM_NT") ? atoi(getenv("FFT_HIP_TEAM_NT")) : 1;
+        static const int nt_mask = FFT_EXP_ENV("FFT_HIP_TEAM_NT") ? atoi(FFT_EXP_ENV("FFT_HIP_TEAM_NT")) : 1;
         tp.nt_mask = nt_mask;
-        static const int tune = getenv("FFT_HIP_TEAM_TUNE") ? atoi(getenv("FFT_HIP_TEAM_TUNE")) : 0;
+        static const int tune = FFT_EXP_ENV("FFT_HIP_TEAM_TUNE") ? atoi(FFT_EXP_ENV("FFT_HIP_TEAM_TUNE")) : 0;
         tp.tune = tune;
-        tp.force_no_teams = getenv("FFT_HIP_TEAM_FORCE_FALLBACK") ? 1 : 0;  // tests: exercise the fallback on a healthy device
+        tp.force_no_teams = team_force_fallback ? 1 : 0;  // test hook (fft_gpu_plan_set_option_hip): exercise the fallback on a healthy device
         tp.trace = team.trace;
         tp.trace_events = team.trace_events;
         tp.scale = scale;
@@ -410,13 +425,13 @@ class Pow2Plan {
         const int log2V = ilog2(V);
         // two interleaved groups per tile (H = 2) were measured: the column pass gains 7 %, every row pass loses
         // 20 %, and the pair is slower than H = 1 at every size tried -- kept behind FFT_HIP_GROUPS=1 for experiments
-        static const int no_groups = getenv("FFT_HIP_GROUPS") ? 0 : 1;
+        static const int no_groups = FFT_EXP_ENV("FFT_HIP_GROUPS") ? 0 : 1;
         int best = -1, best_levels = 2, best_h = 0;
         long long best_c = 0;
         for (int levels = 2; levels <= 3; levels++) {
             p.tw_levels = levels;
             // two interleaved groups pay off for the column pass only (measured: row passes get slower)
-            static const int groups_mask = getenv("FFT_HIP_GROUPS") ? atoi(getenv("FFT_HIP_GROUPS")) : 0;  // bit0 column pass, bit1 row passes
+            static const int groups_mask = FFT_EXP_ENV("FFT_HIP_GROUPS") ? atoi(FFT_EXP_ENV("FFT_HIP_GROUPS")) : 0;  // bit0 column pass, bit1 row passes
             const int want = (p.loadm == fftk::LOAD_CCONTIG) ? (groups_mask & 1) : (groups_mask & 2);
             for (int lh = (p.E == 8 && !no_groups && want) ? 1 : 0; lh >= 0; lh--) {
                 int cand = -1;
@@ -489,7 +504,7 @@ class Pow2Plan {
         // c-contiguous side whose row segments are shorter than 128 B pays seg_cost(); fewer passes win.
         int force[3] = {0, 0, 0};
         int n_force = 0;
-        if (const char* e = getenv("FFT_HIP_FORCE_SPLIT")) n_force = sscanf(e, "%d,%d,%d", &force[0], &force[1], &force[2]);
+        if (const char* e = FFT_EXP_ENV("FFT_HIP_FORCE_SPLIT")) n_force = sscanf(e, "%d,%d,%d", &force[0], &force[1], &force[2]);
         if (n_force > 0 && force[0] + force[1] + force[2] != log2n) n_force = 0;
 
         // ---- candidate: single pass (rows in, rows out)
@@ -516,7 +531,7 @@ class Pow2Plan {
             PassDesc a, b;
             // W_n^(k1 n2) is applied by the column pass (A) to its results; applying it in the row pass (B) at load was
             // measured slower for BOTH kernels (0.78 + 0.59 vs 0.69 + 0.51 ms) -- kept behind FFT_HIP_TWIDDLE_IN_B
-            static const int tw_in_b = getenv("FFT_HIP_TWIDDLE_IN_B") ? 1 : 0;
+            static const int tw_in_b = FFT_EXP_ENV("FFT_HIP_TWIDDLE_IN_B") ? 1 : 0;
             a.log2L = l1; a.E = tile_E(1ll << l1, 1); a.loadm = fftk::LOAD_CCONTIG; a.storem = fftk::STORE_CCONTIG; a.twiddle = tw_in_b ? 0 : 1; a.log2Ntw = log2n;
             b.twiddle = tw_in_b ? 1 : 0; b.log2Ntw = log2n;
             a.in_b = n; a.in_c = 1; a.in_l = 1ll << l2; a.out_b = n; a.out_c = 1; a.out_k = 1ll << l2;
@@ -528,7 +543,7 @@ class Pow2Plan {
             b.n_cols = 1 << l1;
             if (!choose_tile(b, 1ll << l1, budget)) continue;
             b.n_ct = (1 << l1) >> b.log2C;
-            if (!getenv("FFT_HIP_NO_TILE_MAJOR")) {
+            if (!FFT_EXP_ENV("FFT_HIP_NO_TILE_MAJOR")) {
                 // Tile-major scratch: pass A stores each tile (L1 rows x C_A columns) as ONE contiguous block, pass B
                 // gathers its rows from the n2/C_A blocks in chunks of C_B*C_A contiguous elements.  The scratch
                 // layout is ours to choose; this turns pass A's strided write into a linear one.
@@ -592,7 +607,7 @@ class Pow2Plan {
         // row pass with transposed store runs radix-8 (split-radix codelet) stages.
         {
             int auto_fams[3] = {fftk::FAM_R4, fftk::FAM_R4, fftk::FAM_SR16};  // single-pass, column pass, row pass
-            if (const char* e = getenv("FFT_HIP_AUTO_FAMS")) sscanf(e, "%d,%d,%d", &auto_fams[0], &auto_fams[1], &auto_fams[2]);
+            if (const char* e = FFT_EXP_ENV("FFT_HIP_AUTO_FAMS")) sscanf(e, "%d,%d,%d", &auto_fams[0], &auto_fams[1], &auto_fams[2]);
             for (auto& p : passes) {
                 if (algo_ != ALGO_AUTO) p.fam = fam;
                 else if (p.loadm == fftk::LOAD_CCONTIG) p.fam = auto_fams[1];
@@ -630,10 +645,7 @@ class Pow2Plan {
         chunk = batch;
         if (passes.size() > 1) {
             long long target = 1024ll << 20;  // scratch bytes per launch group (FFT_HIP_CHUNK_MB); see DESIGN.md on the Infinity Cache
-            if (const char* e = getenv("FFT_HIP_CHUNK_MB")) {
-                long long mb = atoll(e);
-                if (mb > 0) target = mb << 20;
-            }
+            if (rt->policy.chunk_mb > 0) target = rt->policy.chunk_mb << 20;
             long long per = n * SZ;
             long long c = target / per;
             if (c < 1) c = 1;
@@ -646,7 +658,7 @@ class Pow2Plan {
         if (passes.size() > 1 && algo_ == ALGO_AUTO) {
             build_team(batch);
             if (team.ok && !team_geometry_is_built()) {
-                rt->dfree(team.tables); rt->dfree(team.scratch); rt->dfree(team.ctl);
+                rt->dfree(team.tables); rt->dfree(team.scratch); rt->dfree(team.sticky);
                 team = TeamDesc<T>();
             }
         }
@@ -668,7 +680,7 @@ class Pow2Plan {
         constexpr bool HAS_FIX = (E == 8 && H == 1) &&
                                  ((LM == fftk::LOAD_CCONTIG && FAM == fftk::FAM_R4 && TW) ||
                                   (LM == fftk::LOAD_LCONTIG && SM == fftk::STORE_CCONTIG && FAM == fftk::FAM_SR16 && !TW));
-        static const int use_fixed = getenv("FFT_HIP_FIXED") ? atoi(getenv("FFT_HIP_FIXED")) : 1;
+        static const int use_fixed = FFT_EXP_ENV("FFT_HIP_FIXED") ? atoi(FFT_EXP_ENV("FFT_HIP_FIXED")) : 1;
         if (HAS_FIX && use_fixed) {
             const int full_c = 13 - ilog2(SZ / 8) - p.log2L;  // log2 of (8192 or 4096 elements) / L
             if (p.log2C == full_c) {
@@ -695,7 +707,7 @@ class Pow2Plan {
         if (grid < 0) {
             // persistent grid: exactly the workgroups that are resident at once (occupancy query: VGPRs, LDS, waves)
             int per_cu = rt->max_blocks_per_cu(kernel, p.nthreads, (size_t)p.smem_bytes);
-            static const int force_per_cu = getenv("FFT_HIP_WG_PER_CU") ? atoi(getenv("FFT_HIP_WG_PER_CU")) : 0;  // experiments
+            static const int force_per_cu = FFT_EXP_ENV("FFT_HIP_WG_PER_CU") ? atoi(FFT_EXP_ENV("FFT_HIP_WG_PER_CU")) : 0;  // experiments
             if (force_per_cu > 0) per_cu = force_per_cu;
             if (per_cu < 1) per_cu = 1;
             grid = (long long)rt->num_cus() * per_cu;
@@ -750,15 +762,15 @@ class Pow2Plan {
         tp.inverse = inverse ? 1 : 0;
         tp.scale = scale;
         tp.run_if = run_if;
-        static const int ablate = getenv("FFT_HIP_ABLATE") ? atoi(getenv("FFT_HIP_ABLATE")) : 0;  // profiling only
+        static const int ablate = FFT_EXP_ENV("FFT_HIP_ABLATE") ? atoi(FFT_EXP_ENV("FFT_HIP_ABLATE")) : 0;  // profiling only
         tp.ablate = ablate & ~48;
         if (passes.size() == 2 && ipass == 0) tp.ablate |= (ablate & 16);  // experiment: pass A writes a wrapped (cache-sized) scratch
         if (passes.size() == 2 && ipass == 1) tp.ablate |= (ablate & 32);  // experiment: pass B reads it
-        static const int pair16 = getenv("FFT_HIP_PAIR16") ? atoi(getenv("FFT_HIP_PAIR16")) : 0;
+        static const int pair16 = FFT_EXP_ENV("FFT_HIP_PAIR16") ? atoi(FFT_EXP_ENV("FFT_HIP_PAIR16")) : 0;
         // column pass with narrow (64-byte) row segments: walk the launch transform-fastest (measured 0.64 -> 0.57 ms
         // per 128 transforms at L = 1024; wider-segment shapes and row passes prefer the natural order)
-        static const int order_a = getenv("FFT_HIP_ORDER_A") ? atoi(getenv("FFT_HIP_ORDER_A")) : -1;  // column pass; -1 = auto
-        static const int order_b = getenv("FFT_HIP_ORDER_B") ? atoi(getenv("FFT_HIP_ORDER_B")) : 0;  // row pass
+        static const int order_a = FFT_EXP_ENV("FFT_HIP_ORDER_A") ? atoi(FFT_EXP_ENV("FFT_HIP_ORDER_A")) : -1;  // column pass; -1 = auto
+        static const int order_b = FFT_EXP_ENV("FFT_HIP_ORDER_B") ? atoi(FFT_EXP_ENV("FFT_HIP_ORDER_B")) : 0;  // row pass
         tp.order_g = 0;
         tp.tiles_per_b = 1;
         if (p.n_cols >= 0 && p.n_b_per_transform == 1) {
@@ -780,7 +792,7 @@ class Pow2Plan {
             tp.n_cols = p.n_cols;
             tp.n_tiles = (long long)nb * p.n_b_per_transform * p.n_o * p.n_ct;
         }
-        static const int nonpersistent = getenv("FFT_HIP_NONPERSISTENT") ? 1 : 0;
+        static const int nonpersistent = FFT_EXP_ENV("FFT_HIP_NONPERSISTENT") ? 1 : 0;
         long long grid = nonpersistent ? tp.n_tiles : -1;  // -1: launch_one sizes the persistent grid from the occupancy query
         switch (p.fam) {
             case fftk::FAM_R2: launch_fam<fftk::FAM_R2, 1>(tp, grid, p); break;

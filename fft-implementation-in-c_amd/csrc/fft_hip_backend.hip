@@ -17,6 +17,7 @@
 #include <map>
 #include <new>
 #include <set>
+#include <tuple>
 #include <utility>
 #include <vector>
 
@@ -49,6 +50,8 @@ struct HipRT {
     hipStream_t stream = nullptr;
     int lds_limit = 64 * 1024;
     int cus = 256;
+    bool gfx950 = false;
+    ffteng::EnginePolicy policy;
     std::set<const void*> configured;
 
     void* dmalloc(size_t bytes) {
@@ -66,11 +69,12 @@ struct HipRT {
     void h2d(void* dst, const void* src, size_t bytes) { (void)hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice); }
     int max_lds_bytes() { return lds_limit; }
     int num_cus() { return cus; }
-    std::map<const void*, int> occ_cache;
+    std::map<std::tuple<const void*, int, size_t>, int> occ_cache;  // the answer depends on block size and LDS bytes too
     template <class K>
     int max_blocks_per_cu(K kernel, int threads, size_t smem) {
         const void* key = reinterpret_cast<const void*>(kernel);
-        auto it = occ_cache.find(key);
+        const auto ckey = std::make_tuple(key, threads, smem);
+        auto it = occ_cache.find(ckey);
         if (it != occ_cache.end()) return it->second;
         if (smem > 48 * 1024 && !configured.count(key)) {
             (void)hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, lds_limit);
@@ -83,7 +87,7 @@ struct HipRT {
             n = 1;
         }
         if (n > 8) n = 8;
-        occ_cache[key] = n;
+        occ_cache[ckey] = n;
         return n;
     }
 
@@ -99,12 +103,14 @@ struct HipRT {
     }
 
     void memset_async(void* p, int v, size_t bytes) { (void)hipMemsetAsync(p, v, bytes, stream); }
-    // Team kernel (fft_team.h): built for the MI355X shape, 8 XCDs x 32 CUs, one 512-thread workgroup per CU.  The
-    // kernel verifies the placement itself (HW_REG_XCC_ID); this only says whether the shape can exist here.
+    // Team kernel (fft_team.h): one 512-thread workgroup per CU, 2^log2seats of them on each of n_xcc XCDs.  gfx950 has
+    // 32 CUs per XCD in every partition mode (SPX 256 CUs = 8 XCDs, DPX 128 = 4, QPX 64 = 2, CPX 32 = 1), so the XCD
+    // count follows from the device's CU count.  The kernel verifies the placement itself (HW_REG_XCC_ID, team_form);
+    // this only says which shape to ask for.
     bool team_geometry(int& log2seats, int& n_xcc, int& nthreads) {
-        if (cus != 256) return false;
+        if (!gfx950 || cus < 32 || (cus % 32) != 0 || cus / 32 > 16) return false;
         log2seats = 5;
-        n_xcc = 8;
+        n_xcc = cus / 32;
         nthreads = 512;
         return true;
     }
@@ -117,17 +123,21 @@ struct HipRT {
     // tiles have 64-byte ones.  Measured 125 vs 137 Gpoint/s (the joined halves concentrate twiddles and hand-over in
     // every second tile): an experiment, on only with FFT_HIP_TEAM_ASPLIT=1
     bool team_asplit(int elem_bytes, int log2n) {
-        static const int on = getenv("FFT_HIP_TEAM_ASPLIT") ? atoi(getenv("FFT_HIP_TEAM_ASPLIT")) : 0;
+        static const int on = FFT_EXP_ENV("FFT_HIP_TEAM_ASPLIT") ? atoi(FFT_EXP_ENV("FFT_HIP_TEAM_ASPLIT")) : 0;
         return on && elem_bytes == 8 && log2n == 20;
     }
     // team_defer_kernel (fft_team_defer.h: the last row phase fills the turn of the next transform) instead of
     // team_fft_kernel: +2..8 % at every built size (profiles/r1e_team_variant_sweep.txt).  FFT_HIP_TEAM_DEFER=0 runs the
     // plain kernel.
     bool team_defer(int /*elem_bytes*/, int /*log2n*/) {
-        static const int on = getenv("FFT_HIP_TEAM_DEFER") ? atoi(getenv("FFT_HIP_TEAM_DEFER")) : 1;
+        static const int on = FFT_EXP_ENV("FFT_HIP_TEAM_DEFER") ? atoi(FFT_EXP_ENV("FFT_HIP_TEAM_DEFER")) : 1;
         return on != 0;
     }
-    long long team_timeout_ticks() { return 20000000ll; }  // 0.2 s of the 100 MHz wall clock
+    // 100 MHz wall clock.  Formation: 1 ms -- on a device shared with somebody else's kernel the launch gives up at once
+    // (nothing touched) and the multi-pass plan queued behind it runs.  Team waits: 2 s, a deadlock breaker only: every
+    // member of a formed team is resident and running, so a wait ends when the slowest member gets there.
+    long long team_form_timeout_ticks() { return 100000ll; }
+    long long team_timeout_ticks() { return 200000000ll; }
     template <class K, class... A>
     void launch_coresident(K kernel, long long grid, int block, size_t smem, A... args) {
         launch(kernel, grid, block, smem, args...);  // LDS footprint > 80 KiB: one workgroup per CU, grid == CUs
@@ -150,8 +160,19 @@ pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
 int g_initialized = 0;
 int g_device = 0;
 char g_device_name[256] = "No GPU";
-int g_lds_limit = 64 * 1024;
-int g_num_cus = 256;
+ffteng::EnginePolicy g_policy;  // read from the environment once, at fft_gpu_init_hip
+
+// Per-device facts the planner needs, read from THAT device's properties the first time a plan or buffer is made on it
+// (an 8-GPU process sets each device in turn; nothing is cached from the first device for the others).
+struct DeviceInfo {
+    bool valid = false;
+    int lds_limit = 64 * 1024;
+    int cus = 0;
+    bool gfx950 = false;
+    char name[256];
+};
+enum { MAX_DEVICES = 64 };
+DeviceInfo g_devinfo[MAX_DEVICES];
 
 int probe_device_count() {
     int count = 0;
@@ -160,6 +181,34 @@ int probe_device_count() {
         return 0;
     }
     return count;
+}
+
+// call with g_lock held or from a context that tolerates a benign double fill (the facts are immutable)
+const DeviceInfo* device_info(int dev) {
+    if (dev < 0 || dev >= MAX_DEVICES) return nullptr;
+    DeviceInfo& d = g_devinfo[dev];
+    if (d.valid) return &d;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+        fprintf(stderr, "fft_hip: hipGetDeviceProperties(%d) failed\n", dev);
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    DeviceInfo t;
+    t.gfx950 = strncmp(prop.gcnArchName, "gfx950", 6) == 0;
+    // gfx950: 160 KiB of LDS per workgroup (MI355X_MICROARCH: LDS per CU); other parts: what the runtime reports
+    size_t lds = prop.sharedMemPerBlock;
+    if (t.gfx950 && lds < 160 * 1024) lds = 160 * 1024;
+    if (const char* e = FFT_EXP_ENV("FFT_HIP_LDS_BYTES")) {
+        long v = atol(e);
+        if (v >= 16384) lds = (size_t)v;
+    }
+    t.lds_limit = (int)lds;
+    t.cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 1;
+    snprintf(t.name, sizeof(t.name), "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    t.valid = true;
+    d = t;
+    return &d;
 }
 
 }  // namespace
@@ -205,24 +254,34 @@ template <class Core>
 int team_status_of(Core* core) {
     if (!core) return -1;
     if (!core->team_pending) return core->team_last_status;  // nothing launched since the last look
-    if (!core->team.ctl) return -1;
-    unsigned st = 0;
-    if (hipMemcpy(&st, core->team.ctl + fftk::TEAM_CTL_STATUS, sizeof(st), hipMemcpyDeviceToHost) != hipSuccess) {
+    if (!core->team.ctl || !core->team.sticky) return -1;
+    unsigned st = 0, sticky[2] = {0, 0};
+    if (hipMemcpy(&st, core->team.ctl + fftk::TEAM_CTL_STATUS, sizeof(st), hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(sticky, core->team.sticky, sizeof(sticky), hipMemcpyDeviceToHost) != hipSuccess) {
         (void)hipGetLastError();
         return -1;
     }
+    const int launches = core->team_pending;
     core->team_pending = 0;
+    // the status word is the LAST launch's; the sticky counters cover every launch since the last look (each execute
+    // zeroes the control block, so an earlier execute's TIMEOUT is only visible here)
+    if (sticky[fftk::TEAM_STICKY_TIMEOUTS]) st = fftk::TEAM_STATUS_TIMEOUT;
+    if (sticky[0] || sticky[1]) (void)hipMemset(core->team.sticky, 0, sizeof(sticky));
     core->team_last_status = (int)st;
-    if (st == fftk::TEAM_STATUS_NO_TEAMS) {
-        if (++core->team_fallbacks >= 3) {
+    if (st == fftk::TEAM_STATUS_TIMEOUT) {
+        fprintf(stderr, "fft_hip: a team kernel barrier timed out -- results since the last sync are invalid; this plan "
+                        "continues with the multi-pass schedule\n");
+        core->team.ok = false;  // the buffers stay allocated until the plan is destroyed
+    } else if ((int)sticky[fftk::TEAM_STICKY_FALLBACKS] >= launches && launches > 0) {  // every launch fell back
+        core->team_fallbacks += launches;
+        if (core->team_fallbacks >= 3) {
             fprintf(stderr, "fft_hip: the team kernel could not form its XCD teams three times in a row; this plan "
-                            "continues with the two-pass schedule\n");
-            core->team.ok = false;  // the buffers stay allocated until the plan is destroyed
+                            "continues with the multi-pass schedule\n");
+            core->team.ok = false;
         }
     } else {
         core->team_fallbacks = 0;
     }
-    if (st == fftk::TEAM_STATUS_TIMEOUT) fprintf(stderr, "fft_hip: team kernel barrier timed out -- results of the last execute are invalid\n");
     return (int)st;
 }
 
@@ -277,29 +336,19 @@ int fft_gpu_init_hip(void) {
     // homogeneous MI355X node every device ties, so the current one is that choice.
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) {
-        fprintf(stderr, "fft_hip: hipGetDeviceProperties failed\n");
+    const DeviceInfo* di = device_info(dev);
+    if (!di || hipSetDevice(dev) != hipSuccess) {
         (void)hipGetLastError();
         pthread_mutex_unlock(&g_lock);
         return -1;
     }
-    if (hipSetDevice(dev) != hipSuccess) {
-        pthread_mutex_unlock(&g_lock);
-        return -1;
-    }
     g_device = dev;
-    snprintf(g_device_name, sizeof(g_device_name), "%s (%s, %d CUs)", prop.name, prop.gcnArchName,
-             prop.multiProcessorCount);
-    // gfx950: 160 KiB of LDS per workgroup (MI355X_MICROARCH: LDS per CU); older parts: what the runtime reports
-    size_t lds = prop.sharedMemPerBlock;
-    if (strncmp(prop.gcnArchName, "gfx950", 6) == 0 && lds < 160 * 1024) lds = 160 * 1024;
-    if (const char* e = getenv("FFT_HIP_LDS_BYTES")) {
-        long v = atol(e);
-        if (v >= 16384) lds = (size_t)v;
-    }
-    g_lds_limit = (int)lds;
-    g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    snprintf(g_device_name, sizeof(g_device_name), "%s", di->name);
+    // the production policy knobs, read here and nowhere else (no environment access at plan or execute time)
+    g_policy = ffteng::EnginePolicy();
+    if (const char* e = getenv("FFT_HIP_TEAM")) g_policy.team_mode = atoi(e);
+    if (const char* e = getenv("FFT_HIP_TEAM_MIN_BATCH")) g_policy.team_min_batch = atoi(e);
+    if (const char* e = getenv("FFT_HIP_CHUNK_MB")) g_policy.chunk_mb = atoll(e);
     g_initialized = 1;
     pthread_mutex_unlock(&g_lock);
     return 0;
@@ -399,9 +448,16 @@ fft_gpu_plan_t fft_gpu_plan_1d_ex_hip(int n, int batch, fft_direction dir, fft_p
         delete p;
         return NULL;
     }
+    const DeviceInfo* di = device_info(dev);
+    if (!di) {
+        fft_gpu_destroy_plan_hip(p);
+        return NULL;
+    }
     p->rt.stream = p->own_stream;
-    p->rt.lds_limit = g_lds_limit;
-    p->rt.cus = g_num_cus;
+    p->rt.lds_limit = di->lds_limit;
+    p->rt.cus = di->cus;
+    p->rt.gfx950 = di->gfx950;
+    p->rt.policy = g_policy;
     bool ok = false;
     const int log2n = ffteng::ilog2(n);
     if (p->pow2) {
@@ -482,6 +538,39 @@ int fft_gpu_plan_team_trace_hip(fft_gpu_plan_t p, void* d_trace, int events) {
     if (p->p32) return set(p->p32);
     if (p->p64) return set(p->p64);
     return -1;
+}
+
+// Process-wide planner policy for plans created AFTER the call (a negative argument keeps the current value):
+// team_mode 0 never the team kernel / 1 where it measured faster / 2 every built size; team_min_batch 0 = the measured
+// crossover; chunk_mb 0 = default launch-group size.  fft_gpu_init_hip seeds the same three from the environment
+// (FFT_HIP_TEAM, FFT_HIP_TEAM_MIN_BATCH, FFT_HIP_CHUNK_MB), once.
+int fft_gpu_set_policy_hip(int team_mode, int team_min_batch, int chunk_mb) {
+    pthread_mutex_lock(&g_lock);
+    if (team_mode >= 0) g_policy.team_mode = team_mode;
+    if (team_min_batch >= 0) g_policy.team_min_batch = team_min_batch;
+    if (chunk_mb >= 0) g_policy.chunk_mb = chunk_mb;
+    pthread_mutex_unlock(&g_lock);
+    return 0;
+}
+
+int fft_gpu_plan_set_option_hip(fft_gpu_plan_t p, fft_gpu_plan_option_t option, int value) {
+    if (!p) return -1;
+    auto each_core = [&](auto&& f) {
+        if (p->p32) f(p->p32);
+        if (p->p64) f(p->p64);
+        if (p->b32) f(&p->b32->core);
+        if (p->b64) f(&p->b64->core);
+    };
+    switch (option) {
+        case FFT_GPU_OPT_TEAM_FORCE_FALLBACK:
+            each_core([&](auto* c) { c->team_force_fallback = value != 0; });
+            return 0;
+        case FFT_GPU_OPT_TEAM_ENABLE:
+            each_core([&](auto* c) { c->team.ok = value != 0 && c->team.tables != nullptr; });
+            return 0;
+        default:
+            return -1;
+    }
 }
 
 int fft_gpu_plan_team_status_hip(fft_gpu_plan_t p) {
@@ -611,6 +700,7 @@ int fft_gpu_set_device_hip(int device) {
     HIP_TRY(hipSetDevice(device), return -1);
     pthread_mutex_lock(&g_lock);
     g_device = device;
+    if (const DeviceInfo* di = device_info(device)) snprintf(g_device_name, sizeof(g_device_name), "%s", di->name);
     pthread_mutex_unlock(&g_lock);
     return 0;
 }

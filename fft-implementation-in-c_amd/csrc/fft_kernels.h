@@ -370,8 +370,8 @@ FFT_DEVICE TileCoord<T> tile_coord(const TileParams<T>& p, long long tile) {
     const long long b = rest / (unsigned)p.n_o;
     tc.c0 = ct << p.log2C;
     long long boff_in = b * p.in_b, boff_out = b * p.out_b;
-    if (p.ablate & 16) boff_out %= (8 * p.out_b);  // timing experiment only: scratch side wraps into 8 transforms (cache-resident)
-    if (p.ablate & 32) boff_in %= (8 * p.in_b);
+    if (FFT_ABLATE(p.ablate & 16)) boff_out %= (8 * p.out_b);  // timing experiment only: scratch side wraps into 8 transforms (cache-resident)
+    if (FFT_ABLATE(p.ablate & 32)) boff_in %= (8 * p.in_b);
     tc.in = p.in + boff_in + o * p.in_o + (long long)tc.c0 * p.in_c;
     tc.out = p.out + boff_out + o * p.out_o + (long long)tc.c0 * p.out_c;
     return tc;
@@ -569,9 +569,9 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2((E == 4 ? 1024 : 512), (E == 4 ? FFT_WAVES_PE
         // row pass of a multi-pass plan: the inter-pass twiddle W_N^(k1 * n2) is applied HERE, to the loaded samples
         // (n2 = r + TPC*e runs along the row, k1 = the tile column) -- this pass hides arithmetic behind its memory
         // traffic, the column pass before it does not
-        if (TWIDDLE && LOADM == LOAD_LCONTIG && !(p.ablate & 1)) interpass_twiddle(x, tc.c0, r, j);
+        if (TWIDDLE && LOADM == LOAD_LCONTIG && !FFT_ABLATE(p.ablate & 1)) interpass_twiddle(x, tc.c0, r, j);
 
-        if (!(p.ablate & 2)) {
+        if (!FFT_ABLATE(p.ablate & 2)) {
             FFT_SYNC_LDS();  // staging image / previous tile's last exchange fully consumed
             stockham_all_stages<T, E, FAM, V, H>(x, smem, group_bytes, tw, r, j, log2J, log2TPC, log2L, [&]() {
                 if (!EARLY && have_next) prefetch(tile_ahead, nxt);
@@ -598,7 +598,7 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2((E == 4 ? 1024 : 512), (E == 4 ? FFT_WAVES_PE
 #endif
 
         // ---- inter-pass twiddle (column pass: applied to the results, before the store), scale, inverse swap
-        if (TWIDDLE && LOADM == LOAD_CCONTIG && !(p.ablate & 1)) interpass_twiddle(x, tc.c0, r, j);
+        if (TWIDDLE && LOADM == LOAD_CCONTIG && !FFT_ABLATE(p.ablate & 1)) interpass_twiddle(x, tc.c0, r, j);
         if (p.inverse) {
             FFT_UNROLL
             for (int h = 0; h < H; h++) {

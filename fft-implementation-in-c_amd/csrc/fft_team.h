@@ -49,14 +49,18 @@ namespace fftk {
 
 // control block (32-bit words), zeroed before every launch
 enum {
-    TEAM_CTL_REGISTERED = 0,          // workgroups that have registered
+    TEAM_CTL_REGISTERED = 0,          // workgroups that have registered; TEAM_CTL_POISON set: formation was given up
     TEAM_CTL_STATUS = 1,              // 0 = done by this kernel; 1 = teams could not be formed (nothing touched); 2 = barrier timeout
     TEAM_CTL_COUNT = 32,              // + 32 * xcc : workgroups registered on that XCD (own 128-byte line each)
     TEAM_CTL_FLAGS = 32 + 32 * 16,    // + 32 * team : the team's barrier line, one generation word per member
     TEAM_CTL_MAX_TEAMS = 256,         // 8 XCDs x 32 seats, teams of one
     TEAM_CTL_WORDS = 32 + 32 * 16 + 32 * TEAM_CTL_MAX_TEAMS
 };
+// sticky words: NOT zeroed per launch (a TIMEOUT of any queued execute must survive the next execute's memset of the
+// control block); the host reads and clears them when it syncs (team_status_of)
+enum { TEAM_STICKY_TIMEOUTS = 0, TEAM_STICKY_FALLBACKS = 1, TEAM_STICKY_WORDS = 32 };
 enum { TEAM_STATUS_OK = 0, TEAM_STATUS_NO_TEAMS = 1, TEAM_STATUS_TIMEOUT = 2 };
+constexpr unsigned TEAM_CTL_POISON = 0x80000000u;
 
 template <typename T>
 struct TeamParams {
@@ -65,6 +69,7 @@ struct TeamParams {
     const cpx<T>* tables;    // blob [sa1 | sb1 | sa2 | sb2 | t0 | t1]
     unsigned char* scratch;  // one window pair of 2 * (tile_bytes << log2TS) bytes per team
     unsigned* ctl;
+    unsigned* sticky;        // TEAM_STICKY_WORDS words that survive the per-launch memset of ctl
     int tables_bytes;
     int data_bytes;          // LDS bytes of the data region (stage exchange / row staging image); tables follow
     int log2L1, log2L2, log2CA, log2CB, log2TS;
@@ -74,7 +79,8 @@ struct TeamParams {
     int inverse;
     int o_sb1, o_sa2, o_sb2, o_t0, o_t1;
     int sa1_bits, sa2_bits, t0_bits;
-    long long timeout_ticks;  // bound of every spin, in FFT_CLOCK ticks
+    long long timeout_ticks;       // bound of every team wait, in FFT_CLOCK ticks: a deadlock breaker, never reached by a formed team
+    long long form_timeout_ticks;  // bound of the formation spin: a shared device falls back to the multi-pass plan after this
     int tune;                 // experiments: bit 0 hand-over of phase 2 from the first hook of phase 0 too
     int nt_mask;              // cache policy: bit 0 column-tile DMA nt, bit 1 result stores nt, bit 2 window loads sc1 nt (read once)
     int force_no_teams;       // tests: pretend the placement check failed (exercises the two-pass fallback)
@@ -109,6 +115,57 @@ FFT_DEVICE bool team_all_arrived(unsigned* flags, int TS, unsigned gen, int lane
     return __all((int)(f - gen) >= 0) != 0;
 }
 #endif
+
+// ---- team formation: who shares my L2?  Called by thread 0 of every workgroup; fills sh[0..3] = [slot, xcc, ok, 0].
+// The decision is ATOMIC for the whole launch: a workgroup proceeds only if it loads REGISTERED == the grid size,
+// unpoisoned; a workgroup that gives up (the device is shared: not everybody became resident within the formation
+// timeout) poisons the word with a compare-and-swap that fails once the count is complete -- so either every
+// workgroup sees the complete count and runs as a team member, or every one sees the poison (a late arrival's add
+// lands on a poisoned word and can never make it equal the grid size) and leaves before touching anything; the
+// multi-pass plan queued behind the kernel reads STATUS == NO_TEAMS and does the work.
+template <typename T>
+FFT_DEVICE void team_form(const TeamParams<T>& p, unsigned* sh) {
+    FFT_TEST_DELAY();
+    const unsigned xcc = FFT_XCC_ID(p.n_xcc);
+    const unsigned slot = FFT_ATOMIC_ADD_AGENT(&p.ctl[TEAM_CTL_COUNT + 32 * xcc], 1u);
+    FFT_ATOMIC_ADD_AGENT(&p.ctl[TEAM_CTL_REGISTERED], 1u);
+    const unsigned nblocks = (unsigned)FFT_NBLOCKS;
+    unsigned ok = 0;
+    const long long t0 = FFT_CLOCK();
+    for (;;) {
+        const unsigned v = FFT_ATOMIC_LOAD_AGENT(&p.ctl[TEAM_CTL_REGISTERED]);
+        if (v == nblocks) { ok = 1; break; }
+        if (v & TEAM_CTL_POISON) break;
+        if (FFT_CLOCK() - t0 > p.form_timeout_ticks) {
+            const unsigned found = FFT_ATOMIC_CAS_AGENT(&p.ctl[TEAM_CTL_REGISTERED], v, v | TEAM_CTL_POISON);
+            if (found == v) break;  // poisoned by me
+            continue;               // the word moved on (another registration, the last one, or somebody's poison): look again
+        }
+        FFT_SLEEP();
+    }
+    if (ok) {  // every workgroup has registered: the per-XCD counts are final and the same for every reader
+        for (int x = 0; x < 16; x++) {
+            const unsigned cnt = FFT_ATOMIC_LOAD_AGENT(&p.ctl[TEAM_CTL_COUNT + 32 * x]);
+            if (cnt != (x < p.n_xcc ? (1u << p.log2seats) : 0u)) ok = 0;
+        }
+    }
+    if (p.force_no_teams) ok = 0;
+    if (!ok && FFT_ATOMIC_CAS_AGENT(&p.ctl[TEAM_CTL_STATUS], 0u, (unsigned)TEAM_STATUS_NO_TEAMS) == 0u)
+        FFT_ATOMIC_ADD_AGENT(&p.sticky[TEAM_STICKY_FALLBACKS], 1u);  // once per launch
+    sh[0] = slot;
+    sh[1] = xcc;
+    sh[2] = ok;
+    sh[3] = 0;  // set when a team wait timed out: later waits return at once, the status word tells the host
+}
+
+// A team wait ran into its bound (cannot happen to a formed team short of a hardware fault; the bound keeps a broken
+// launch from hanging the device): results are invalid.  STATUS never goes back from TIMEOUT, NO_TEAMS is not
+// overwritten (CAS from 0), and the sticky counter tells the host even if later executes zero the control block.
+template <typename T>
+FFT_DEVICE void team_report_timeout(const TeamParams<T>& p) {
+    FFT_ATOMIC_CAS_AGENT(&p.ctl[TEAM_CTL_STATUS], 0u, (unsigned)TEAM_STATUS_TIMEOUT);
+    FFT_ATOMIC_ADD_AGENT(&p.sticky[TEAM_STICKY_TIMEOUTS], 1u);
+}
 
 #define FFT_TEAM_GEO(l1, l2, ca, cb, ts) ((l1) | ((l2) << 5) | ((ca) << 10) | ((cb) << 15) | ((ts) << 20))
 
@@ -304,32 +361,7 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
     twB.log2L = log2L2;
 
     // ---- team formation: who shares my L2?
-    if (tid_invariant == 0) {
-        const unsigned xcc = FFT_XCC_ID(p.n_xcc);
-        const unsigned slot = FFT_ATOMIC_ADD_AGENT(&p.ctl[TEAM_CTL_COUNT + 32 * xcc], 1u);
-        FFT_ATOMIC_ADD_AGENT(&p.ctl[TEAM_CTL_REGISTERED], 1u);
-        unsigned ok = 1;
-        const long long t0 = FFT_CLOCK();
-        while (FFT_ATOMIC_LOAD_AGENT(&p.ctl[TEAM_CTL_REGISTERED]) < (unsigned)FFT_NBLOCKS) {
-            if (FFT_ATOMIC_LOAD_AGENT(&p.ctl[TEAM_CTL_STATUS]) != 0 || FFT_CLOCK() - t0 > p.timeout_ticks) {
-                ok = 0;  // not every workgroup is resident (the device is shared): give up before touching anything
-                break;
-            }
-            FFT_SLEEP();
-        }
-        if (ok) {
-            for (int x = 0; x < 16; x++) {
-                const unsigned cnt = FFT_ATOMIC_LOAD_AGENT(&p.ctl[TEAM_CTL_COUNT + 32 * x]);
-                if (cnt != (x < p.n_xcc ? (1u << p.log2seats) : 0u)) ok = 0;
-            }
-        }
-        if (p.force_no_teams) ok = 0;
-        if (!ok) FFT_ATOMIC_STORE_AGENT(&p.ctl[TEAM_CTL_STATUS], (unsigned)TEAM_STATUS_NO_TEAMS);
-        sh[0] = slot;
-        sh[1] = xcc;
-        sh[2] = ok;
-        sh[3] = 0;  // set when a team wait timed out: later waits return at once, the status word tells the host
-    }
+    if (tid_invariant == 0) team_form(p, sh);
     FFT_SYNC();
     FFT_LDS_FRESH();
     if (!sh[2]) return;
@@ -365,7 +397,7 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
             while (COUNTER ? (int)(FFT_L2_COUNT_POLL(flags) - (g << log2TS)) < 0
                            : !team_all_arrived(flags, TS, g, tid_invariant & (FFT_TEAM_POLL_LANES - 1))) {
                 if (FFT_CLOCK() - t0 > p.timeout_ticks) {
-                    FFT_ATOMIC_STORE_AGENT(&p.ctl[TEAM_CTL_STATUS], (unsigned)TEAM_STATUS_TIMEOUT);
+                    team_report_timeout(p);
                     sh[3] = 1;
                     break;
                 }
@@ -399,7 +431,7 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
         const int c0 = column_block(t) << log2CA;  // the team's workgroups read one contiguous TS*CA-column band
         const cpx<T>* src = inb + ((long long)(tid >> log2CPR) << log2L2) + c0 + V16 * (tid & ((1 << log2CPR) - 1));
         const long long step = (long long)(nthreads >> log2CPR) << log2L2;  // rows per wave-front of chunks
-        if (p.ablate & 8) return;  // profiling: no input stream
+        if (FFT_ABLATE(p.ablate & 8)) return;  // profiling: no input stream
         if (p.nt_mask & 1) {  // one branch per call, not one per chunk
             FFT_UNROLL
             for (int i = 0; i < NCH; i++)
@@ -525,7 +557,7 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
             FFT_SYNC_LDS();   // ... everybody's has; the work image is free (previous tile's last stage has read it)
             ev();  // A: tile landed
             const bool more = (t + 1 < NT);
-            if (!(p.ablate & 2)) {
+            if (!FFT_ABLATE(p.ablate & 2)) {
                 team_all_stages<T, E>(x, land, work, twA, rA, jA, log2CA, log2TPCA, log2L1, [&](int s, int total) {
                     // the next tile flies during the remaining stages; issued in two halves (a CU's memory queue is short)
                     if (more) {
@@ -537,7 +569,7 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
                 FFT_SYNC_LDS();
                 dma_column_tile(inb, t + 1, 0, NCH);
             }
-            if (!(p.ablate & 1)) {  // W_n^(k1 n2), two-level LDS table
+            if (!FFT_ABLATE(p.ablate & 1)) {  // W_n^(k1 n2), two-level LDS table
                 const unsigned n2 = (unsigned)(column_block(t) << log2CA) + (unsigned)jA;
                 team_interpass_twiddle<T, E>(x, tab + p.o_t0, tab + p.o_t1, p.t0_bits, (unsigned)rA * n2, n2 << log2TPCA);
             }
@@ -594,7 +626,7 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
                 }
                 // hand-over of phase ph+2: as early as its wait allows, so that the stores are long in L2 when the phase
                 // closes -- phase 0 gives the others one more stage to report their read of phase 0 (a1)
-                if (s == ((total >= 2 && ph == 0 && !(p.tune & 1)) ? 1 : 0)) {
+                if (s == ((total >= 2 && ph == 0 && !FFT_ABLATE(p.tune & 1)) ? 1 : 0)) {
                     if constexpr (NK > 0) {
                         if (ph + 2 < NT) {  // hand over phase ph+2 into the window phase ph was read from
                             if (ph == 0) wait_all(g0 + 1);  // everybody has read phase 0 (phase 1: known since the wait above)
@@ -631,7 +663,7 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
                     }
                 }
             };
-            if (!(p.ablate & 2)) {
+            if (!FFT_ABLATE(p.ablate & 2)) {
                 team_all_stages<T, E>(x, land, work, twB, rB, jB, log2CB, log2TPCB, log2L2, traffic, false);
             } else {
                 FFT_SYNC_LDS();
@@ -658,7 +690,7 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
                 for (int q = 0; q < E / 2; q++) pair_rows<T>(x[0][2 * q][0], x[0][2 * q + 1][0], odd, 1, v[q]);
                 vec16<T>* const dst0 = reinterpret_cast<vec16<T>*>(outb + ((long long)(rB + ((odd ? 1 : 0) << log2TPCB)) << log2L1) + k1 + (jB & ~1));
                 const long long dstep = (2ll << (log2TPCB + log2L1)) / V16;  // two slots further on, in 16-byte units
-                if (p.ablate & 4) {  // profiling: no result stream
+                if (FFT_ABLATE(p.ablate & 4)) {  // profiling: no result stream
                 } else if (p.nt_mask & 2) {
                     FFT_UNROLL
                     for (int q = 0; q < E / 2; q++) FFT_STORE16_NT(dst0 + q * dstep, v[q]);

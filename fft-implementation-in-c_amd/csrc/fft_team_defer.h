@@ -69,33 +69,8 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
     twB.sa_bits = team_stage_table_bits(SZ, log2L2);
     twB.log2L = log2L2;
 
-    // ---- team formation (as in team_fft_kernel)
-    if (tid_invariant == 0) {
-        const unsigned xcc = FFT_XCC_ID(p.n_xcc);
-        const unsigned slot = FFT_ATOMIC_ADD_AGENT(&p.ctl[TEAM_CTL_COUNT + 32 * xcc], 1u);
-        FFT_ATOMIC_ADD_AGENT(&p.ctl[TEAM_CTL_REGISTERED], 1u);
-        unsigned ok = 1;
-        const long long t0 = FFT_CLOCK();
-        while (FFT_ATOMIC_LOAD_AGENT(&p.ctl[TEAM_CTL_REGISTERED]) < (unsigned)FFT_NBLOCKS) {
-            if (FFT_ATOMIC_LOAD_AGENT(&p.ctl[TEAM_CTL_STATUS]) != 0 || FFT_CLOCK() - t0 > p.timeout_ticks) {
-                ok = 0;
-                break;
-            }
-            FFT_SLEEP();
-        }
-        if (ok) {
-            for (int x = 0; x < 16; x++) {
-                const unsigned cnt = FFT_ATOMIC_LOAD_AGENT(&p.ctl[TEAM_CTL_COUNT + 32 * x]);
-                if (cnt != (x < p.n_xcc ? (1u << p.log2seats) : 0u)) ok = 0;
-            }
-        }
-        if (p.force_no_teams) ok = 0;
-        if (!ok) FFT_ATOMIC_STORE_AGENT(&p.ctl[TEAM_CTL_STATUS], (unsigned)TEAM_STATUS_NO_TEAMS);
-        sh[0] = slot;
-        sh[1] = xcc;
-        sh[2] = ok;
-        sh[3] = 0;
-    }
+    // ---- team formation (team_form, fft_team.h)
+    if (tid_invariant == 0) team_form(p, sh);
     FFT_SYNC();
     FFT_LDS_FRESH();
     if (!sh[2]) return;
@@ -128,7 +103,7 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
             const long long t0 = FFT_CLOCK();
             while ((int)(FFT_L2_COUNT_POLL(flags) - ((unsigned)g << log2TS)) < 0) {
                 if (FFT_CLOCK() - t0 > p.timeout_ticks) {
-                    FFT_ATOMIC_STORE_AGENT(&p.ctl[TEAM_CTL_STATUS], (unsigned)TEAM_STATUS_TIMEOUT);
+                    team_report_timeout(p);
                     sh[3] = 1;
                     break;
                 }

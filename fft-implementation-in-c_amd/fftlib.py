@@ -57,6 +57,7 @@ SIGNATURES = {
     "fft_gpu_memory_bytes_hip": (_sz, [_vp]), "fft_gpu_plan_1d_ex_hip": (_vp, [_i, _i, _i, _i, _i]),
     "fft_gpu_plan_info_hip": (_i, [_vp, C.POINTER(PlanInfo)]), "fft_gpu_plan_set_stream_hip": (_i, [_vp, _vp]),
     "fft_gpu_execute_ptr_hip": (_i, [_vp, _vp, _vp]), "fft_gpu_plan_sync_hip": (_i, [_vp]),
+    "fft_gpu_plan_set_option_hip": (_i, [_vp, _i, _i]), "fft_gpu_set_policy_hip": (_i, [_i, _i, _i]),
     "fft_gpu_plan_team_status_hip": (_i, [_vp]), "fft_gpu_plan_team_trace_hip": (_i, [_vp, _vp, _i]),
     "fft_gpu_execute_timed_hip": (_i, [_vp, _vp, _vp, _i, C.POINTER(C.c_float)]),
     "fft_gpu_dft_1d_batch_hip": (_i, [_vp, _vp, _i, _i, _i, _i]),
@@ -120,6 +121,15 @@ def init():
     return lib
 
 
+EXP_LIB_PATH = os.path.join(HERE, "libfft_mi355x_exp.so")  # -DFFT_EXPERIMENTS build: kernel-variant switches, ablation bits
+OPT_TEAM_FORCE_FALLBACK, OPT_TEAM_ENABLE = 1, 2
+
+
+def set_policy(team=-1, min_batch=-1, chunk_mb=-1):
+    """Planner policy for plans created from now on (fft_gpu_set_policy_hip); -1 keeps a value."""
+    load().fft_gpu_set_policy_hip(team, min_batch, chunk_mb)
+
+
 class DeviceBuffer:
     """Device memory owned through fft_gpu_alloc_bytes_hip / fft_gpu_free."""
 
@@ -179,7 +189,11 @@ class Plan:
             raise RuntimeError("fft_gpu_execute_ptr failed")
 
     def sync(self):
-        self.lib.fft_gpu_plan_sync(self.handle)
+        return self.lib.fft_gpu_plan_sync(self.handle)
+
+    def set_option(self, option, value):
+        if self.lib.fft_gpu_plan_set_option_hip(self.handle, option, value) != 0:
+            raise RuntimeError("fft_gpu_plan_set_option_hip(%d) failed" % option)
 
     def team_status(self):
         """0 team kernel did the last execute, 1 its fallback did, 2 barrier timeout, -1 no team kernel / never launched."""

@@ -87,6 +87,13 @@ typedef struct {
                            described by n_passes/factors is queued behind it as its fallback */
 } fft_gpu_plan_info_t;
 
+/* Per-plan switches (tests and integrators; nothing here changes results) */
+typedef enum {
+    FFT_GPU_OPT_TEAM_FORCE_FALLBACK = 1, /* 1: the team kernel behaves as if it could not form its XCD teams (status 1, nothing
+                                            touched) and the multi-pass plan queued behind it does the work */
+    FFT_GPU_OPT_TEAM_ENABLE = 2          /* 0: run the multi-pass schedule only; 1: back to the team kernel where the plan has one */
+} fft_gpu_plan_option_t;
+
 /* backend-level additive entry points */
 int fft_gpu_device_count_hip(void);
 int fft_gpu_set_device_hip(int device);
@@ -101,6 +108,12 @@ int fft_gpu_plan_info_hip(fft_gpu_plan_t plan, fft_gpu_plan_info_t* info);
 int fft_gpu_plan_set_stream_hip(fft_gpu_plan_t plan, void* hip_stream); /* NULL = the plan's own stream */
 int fft_gpu_execute_ptr_hip(fft_gpu_plan_t plan, const void* d_in, void* d_out); /* async on the plan's stream */
 int fft_gpu_plan_sync_hip(fft_gpu_plan_t plan);
+int fft_gpu_plan_set_option_hip(fft_gpu_plan_t plan, fft_gpu_plan_option_t option, int value);
+/* planner policy for plans created after the call; a negative argument keeps the current value.  team_mode: 0 never
+ * the team kernel, 1 (default) where it measured faster than the multi-pass schedule, 2 every size it is built for;
+ * team_min_batch: 0 = the measured batch crossover; chunk_mb: 0 = the default multi-pass launch-group size.
+ * fft_gpu_init seeds them once from FFT_HIP_TEAM / FFT_HIP_TEAM_MIN_BATCH / FFT_HIP_CHUNK_MB. */
+int fft_gpu_set_policy_hip(int team_mode, int team_min_batch, int chunk_mb);
 /* syncs the plan's stream, then: 0 the last execute was done by the team kernel, 1 its XCD teams could not be
  * formed and the multi-pass fallback did the work, 2 a team barrier timed out (results invalid; plan_sync returns -1
  * too), -1 the plan has no team kernel or it has never been launched */

@@ -8,7 +8,7 @@
  * Parity status: PINNED.  Every function below that has a reference
  * counterpart is checked bit-for-bit (recurrence variants) against the real
  * reference compiled from /root/reference by oracle/Makefile (target `ref`,
- * output oracle/_ref/libref.so), see tests/test_oracle_vs_ref.py, and against
+ * output oracle/_ref/libref.so), see tests/test_oracle.py::test_against_real_reference_when_present, and against
  * the golden vectors under tests/golden/ that were generated from that build
  * (tests/golden/make_golden.py).
  *

@@ -17,8 +17,8 @@ def _ensure_product_lib():
     there they BUILD it (hipcc cross-compiles gfx950 without a GPU), exactly like __graft_entry__.build()."""
     import subprocess
     pkg = os.path.join(ROOT, "fft-implementation-in-c_amd")
-    if not os.path.exists(os.path.join(pkg, "libfft_mi355x.so")):
-        subprocess.run(["make", "-s", "-C", pkg], check=True)
+    if not (os.path.exists(os.path.join(pkg, "libfft_mi355x.so")) and os.path.exists(os.path.join(pkg, "libfft_mi355x_exp.so"))):
+        subprocess.run(["make", "-s", "-j2", "-C", pkg], check=True)
 
 
 def pytest_sessionstart(session):
@@ -38,3 +38,13 @@ def gpu_lib():
     import fftlib
     lib = fftlib.init()
     return lib
+
+
+@pytest.fixture(autouse=True)
+def _default_planner_policy(request):
+    """GPU tests steer the planner with fftlib.set_policy(); every test starts from and leaves the default policy."""
+    yield
+    if request.node.get_closest_marker("gpu") is not None:
+        import fftlib
+        if fftlib._lib is not None:
+            fftlib.set_policy(team=1, min_batch=0, chunk_mb=0)

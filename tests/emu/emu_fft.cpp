@@ -1,5 +1,7 @@
 // emu_fft.cpp -- compiles the engine + kernels for the CPU emulation and
 // exports a tiny C API for pytest (ctypes).  TEST INFRASTRUCTURE ONLY.
+#include <time.h>
+
 #include "emu_runtime.h"
 #include "fft_engine.h"
 
@@ -21,6 +23,15 @@ long long clock_ticks() {  // 100 MHz, like the device's wall clock
 }
 
 static thread_local unsigned* g_xchg = nullptr;  // 1024 words per workgroup
+
+// test hook (FFT_TEST_DELAY in team_form): workgroup FFT_EMU_LATE_BLOCK sleeps FFT_EMU_LATE_MS before it registers
+void test_delay() {
+    const char* b = getenv("FFT_EMU_LATE_BLOCK");
+    const char* ms = getenv("FFT_EMU_LATE_MS");
+    if (!b || !ms || (unsigned)atoi(b) != blockIdx_.x) return;
+    struct timespec ts = {atoi(ms) / 1000, (long)(atoi(ms) % 1000) * 1000000l};
+    nanosleep(&ts, nullptr);
+}
 
 unsigned shfl_xor_u32(unsigned v, int mask) {
     unsigned* xchg = g_xchg;
@@ -108,6 +119,10 @@ static int run(const void* in, void* out, int n, int batch, int dir, int algo, i
             info[6] = plan.team.ok ? (plan.team.asplit ? 1 : 0) + (plan.team.defer ? 2 : 0) : 0;
         }
         plan.execute((const C*)in, (C*)out, batch, dir > 0);
+        if (info && plan.team.ctl) {  // what the team kernel reported (the emulation's memory is the host's)
+            info[5] = 1 + (int)plan.team.ctl[fftk::TEAM_CTL_STATUS] + 10 * (int)plan.team.sticky[fftk::TEAM_STICKY_FALLBACKS] +
+                      100 * (int)plan.team.sticky[fftk::TEAM_STICKY_TIMEOUTS];
+        }
     } else {
         ffteng::BluesteinPlan<T, emu::Runtime> plan;
         if (!plan.build(&rt, n, dir, algo, batch)) return -1;

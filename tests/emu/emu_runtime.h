@@ -14,6 +14,19 @@
 
 namespace emu {
 
+// mirror of ffteng::EnginePolicy for the emulation (fft_engine.h is included after this header); the tests steer it
+// through the same environment variables the product reads at fft_gpu_init_hip
+struct ffteng_policy {
+    int team_mode = 1;
+    int team_min_batch = 0;
+    long long chunk_mb = 0;
+    ffteng_policy() {
+        if (const char* e = getenv("FFT_HIP_TEAM")) team_mode = atoi(e);
+        if (const char* e = getenv("FFT_HIP_TEAM_MIN_BATCH")) team_min_batch = atoi(e);
+        if (const char* e = getenv("FFT_HIP_CHUNK_MB")) chunk_mb = atoll(e);
+    }
+};
+
 struct Runtime {
     void* dmalloc(size_t bytes) { return malloc(bytes ? bytes : 16); }
     void dfree(void* p) { free(p); }
@@ -38,6 +51,13 @@ struct Runtime {
     bool team_defer(int, int) { return getenv("FFT_EMU_TEAM_PLAIN") == nullptr; }  // the shipped default; FFT_EMU_TEAM_PLAIN: team_fft_kernel
     bool team_asplit(int, int) { return getenv("FFT_EMU_TEAM_ASPLIT") != nullptr; }
     long long team_timeout_ticks() { return 60ll * 100000000ll; }
+    // formation: generous by default (host threads start slowly); FFT_EMU_FORM_TIMEOUT_MS makes it short for the test
+    // that delays one workgroup past it
+    long long team_form_timeout_ticks() {
+        const char* e = getenv("FFT_EMU_FORM_TIMEOUT_MS");
+        return e ? atoll(e) * 100000ll : 60ll * 100000000ll;
+    }
+    ffteng_policy policy;
     int team_grid_skew() { return (team_mode >> 20) & 1; }
     template <class K>
     int max_blocks_per_cu(K, int, size_t) { return 1; }

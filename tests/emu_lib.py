@@ -25,7 +25,7 @@ def lib():
     if _lib is None:
         so = os.environ.get("FFT_EMU_SO", os.path.join(EMU_DIR, "libfft_emu.so"))  # FFT_EMU_SO: a sanitizer build
         if "FFT_EMU_SO" not in os.environ and _needs_build(so):
-            subprocess.run(["g++", "-O1", "-std=c++17", "-DFFT_EMU", "-fPIC", "-shared", "-pthread", "-I" + CSRC,
+            subprocess.run(["g++", "-O1", "-std=c++17", "-DFFT_EMU", "-DFFT_EXPERIMENTS", "-fPIC", "-shared", "-pthread", "-I" + CSRC,
                             os.path.join(EMU_DIR, "emu_fft.cpp"), "-o", so], check=True)
         _lib = C.CDLL(so)
         _lib.emu_fft.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

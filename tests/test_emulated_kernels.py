@@ -151,6 +151,47 @@ def test_team_kernel_fallback_when_teams_cannot_form():
         assert rel(y, oracle(x, -1)) < TOL[np.complex64]
 
 
+def test_team_kernel_status_words():
+    """info[5] = 1 + STATUS + 10 * sticky fallbacks + 100 * sticky timeouts: a healthy launch reports 1, a launch that
+    could not form its teams 1 + 1 + 10 (exactly one workgroup counts the fallback)."""
+    x = O.gen_lcg(4096, 2, 3).astype(np.complex64)
+    _, info = E.emu_fft_team(x, -1, log2seats=2, n_xcc=2, threads=16, lds_budget=16384)
+    assert info[5] == 1
+    _, info = E.emu_fft_team(x, -1, log2seats=2, n_xcc=2, threads=16, lds_budget=16384, skew=True)
+    assert info[5] == 12
+
+
+@pytest.mark.parametrize("plain", [False, True])
+@pytest.mark.parametrize("late_block", [0, 5])
+def test_team_kernel_late_workgroup_cannot_split_the_launch(late_block, plain, monkeypatch):
+    """One workgroup becomes resident only after the formation timeout (a device shared with somebody else's kernel).
+    The decision must be the same for every workgroup: the ones that waited poison the registration word and leave,
+    the late one finds the poison and leaves too -- nobody runs as a team member, nothing is touched (the in-place
+    input survives), status = NO_TEAMS, and the multi-pass plan queued behind the kernel produces the result."""
+    if plain:
+        monkeypatch.setenv("FFT_EMU_TEAM_PLAIN", "1")
+    monkeypatch.setenv("FFT_EMU_FORM_TIMEOUT_MS", "30")
+    monkeypatch.setenv("FFT_EMU_LATE_BLOCK", str(late_block))
+    monkeypatch.setenv("FFT_EMU_LATE_MS", "400")
+    x = O.gen_lcg(4096, 4, 5).astype(np.complex64)
+    for inplace in (False, True):
+        y, info = E.emu_fft_team(x, -1, log2seats=2, n_xcc=2, threads=16, lds_budget=16384, inplace=inplace)
+        assert info[0] >= 400
+        assert info[5] == 12, "status must be NO_TEAMS, counted once, no timeout"
+        assert rel(y, oracle(x, -1)) < TOL[np.complex64]
+
+
+def test_team_kernel_slow_start_inside_the_timeout_still_forms_teams(monkeypatch):
+    """A workgroup that registers late but inside the formation timeout: the launch proceeds as a team."""
+    monkeypatch.setenv("FFT_EMU_FORM_TIMEOUT_MS", "5000")
+    monkeypatch.setenv("FFT_EMU_LATE_BLOCK", "3")
+    monkeypatch.setenv("FFT_EMU_LATE_MS", "200")
+    x = O.gen_lcg(4096, 4, 5).astype(np.complex64)
+    y, info = E.emu_fft_team(x, -1, log2seats=2, n_xcc=2, threads=16, lds_budget=16384)
+    assert info[5] == 1
+    assert rel(y, oracle(x, -1)) < TOL[np.complex64]
+
+
 @pytest.mark.parametrize("dtype,threads", [(np.complex64, 64), (np.complex128, 128)])
 def test_team_kernel_three_stage_rows(dtype, threads, monkeypatch):
     """32 x 512 split: the row FFTs have three stages, so the hand-over of phase ph+2 and the next tile's DMA are

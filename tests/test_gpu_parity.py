@@ -1,6 +1,6 @@
 """GPU parity tests: the HIP engine, called through the C ABI, against the CPU
 oracle (oracle/oracle_fft.c = restatement of the reference's radix-2 path,
-pinned bit-exact to the real reference in tests/test_oracle_vs_ref.py) and
+pinned bit-exact to the real reference in tests/test_oracle.py) and
 against the golden vectors generated from the real reference.
 
 Tolerances (BASELINE.json north_star): rel-L2 <= 1e-6 for fp64, <= 1e-4 for fp32.
@@ -363,7 +363,7 @@ def test_batch_larger_than_one_launch_group(gpu_lib):
     import fftlib
     n, batch = 1 << 16, 40
     x = lcg(n, batch, np.complex64, seed=11)
-    os.environ["FFT_HIP_CHUNK_MB"] = "4"
+    fftlib.set_policy(chunk_mb=4)
     try:
         plan = fftlib.Plan(n, batch, -1, np.complex64)
         assert plan.info().chunk_batch == 8
@@ -374,7 +374,7 @@ def test_batch_larger_than_one_launch_group(gpu_lib):
             for b in range(batch):
                 assert rel(y[b], ref[b]) <= 2e-6, (d, b)
     finally:
-        del os.environ["FFT_HIP_CHUNK_MB"]
+        fftlib.set_policy(chunk_mb=0)
 
 
 @pytest.mark.parametrize("log2n", [21, 22, 24])
@@ -470,7 +470,7 @@ def test_full_size_config4_shard_and_config5(gpu_lib):
 # ---------------------------------------------------------------------------
 def _team_plan(monkeypatch, n, batch, direction, dtype, mode="2"):
     import fftlib
-    monkeypatch.setenv("FFT_HIP_TEAM", mode)
+    fftlib.set_policy(team=int(mode))  # tests/conftest.py puts the default policy back after every test
     plan = fftlib.Plan(n, batch, direction, dtype)
     return plan
 
@@ -505,7 +505,7 @@ def test_team_kernel_vs_oracle(gpu_lib, monkeypatch, log2n, dtype):
         assert plan.team_status() == 0
         assert np.array_equal(buf.download(x.shape, dtype), y)
         # the multi-pass schedule computes the same spectrum
-        monkeypatch.setenv("FFT_HIP_TEAM", "0")
+        fftlib.set_policy(team=0)
         plan2 = fftlib.Plan(n, batch, d, dtype)
         assert plan2.info().team_tiles == 0
         buf.upload(x)
@@ -522,7 +522,7 @@ def test_team_kernel_default_policy_and_full_size(gpu_lib, monkeypatch):
     """BASELINE configs[2] as bench.py runs it: N = 2^20 fp32 x 512 takes the team kernel by default; every one of
     the 512 spectra is checked against the analytic two-tone answer; a batch of 64 keeps the two-pass schedule."""
     import fftlib
-    monkeypatch.delenv("FFT_HIP_TEAM", raising=False)
+    fftlib.set_policy(team=1, min_batch=0)
     n, batch = 1 << 20, 512
     small = fftlib.Plan(n, 64, -1, np.complex64)
     assert small.info().team_tiles == 4  # planned ...
@@ -562,13 +562,13 @@ def test_team_kernel_default_policy_and_full_size(gpu_lib, monkeypatch):
 
 
 def test_team_kernel_fallback_on_device(gpu_lib, monkeypatch):
-    """FFT_HIP_TEAM_FORCE_FALLBACK makes the kernel's placement check fail on a healthy device: status 1, nothing
+    """FFT_GPU_OPT_TEAM_FORCE_FALLBACK makes the kernel's placement check fail on a healthy device: status 1, nothing
     touched by the team kernel, the two-pass launches queued behind it deliver the (in-place) result; after three
     fallbacks in a row the plan stops launching the team kernel."""
     import fftlib
-    monkeypatch.setenv("FFT_HIP_TEAM_FORCE_FALLBACK", "1")
     n, batch = 1 << 20, 16
     plan = _team_plan(monkeypatch, n, batch, -1, np.complex64)
+    plan.set_option(fftlib.OPT_TEAM_FORCE_FALLBACK, 1)
     x = lcg(n, batch, np.complex64, seed=9)
     buf = fftlib.DeviceBuffer(x.nbytes)
     ref = O.oracle_fft(x[:2].astype(np.complex128), -1, "dit")
@@ -588,7 +588,7 @@ def test_team_kernel_repeatable_bit_for_bit(gpu_lib, monkeypatch):
     24 back-to-back executes of two team geometries must reproduce the first result bit for bit (tools/team_stress.py
     is the long version: 300 executes of up to 4 GiB each)."""
     import fftlib
-    monkeypatch.setenv("FFT_HIP_TEAM", "2")
+    fftlib.set_policy(team=2)
     for log2n, batch in ((20, 96), (18, 259)):
         n = 1 << log2n
         x = lcg(n, batch, np.complex64, seed=batch)
@@ -616,7 +616,7 @@ def test_team_kernels_of_two_plans_on_two_streams(gpu_lib, monkeypatch):
     formation of both gives up after its bounded wait and the multi-pass fallbacks run), both results must be right
     and nothing may hang."""
     import fftlib
-    monkeypatch.setenv("FFT_HIP_TEAM", "2")
+    fftlib.set_policy(team=2)
     n, batch = 1 << 18, 64
     xs = [lcg(n, batch, np.complex64, seed=s) for s in (21, 22)]
     plans = [fftlib.Plan(n, batch, -1, np.complex64) for _ in xs]
@@ -670,7 +670,9 @@ def test_team_kernel_forced_variants(gpu_lib, defer, nt):
         "    buf.free()\n"
         "print('ok')\n"
     ) % (os.path.join(ROOT, "fft-implementation-in-c_amd"), os.path.join(ROOT, "tests"))
-    env = dict(os.environ, FFT_HIP_TEAM="2", FFT_HIP_TEAM_DEFER=defer, FFT_HIP_TEAM_NT=nt)
+    # kernel-variant switches exist only in the -DFFT_EXPERIMENTS build of the library
+    env = dict(os.environ, FFT_HIP_TEAM="2", FFT_HIP_TEAM_DEFER=defer, FFT_HIP_TEAM_NT=nt,
+               FFT_LIB_PATH=os.path.join(ROOT, "fft-implementation-in-c_amd", "libfft_mi355x_exp.so"))
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
 
@@ -700,6 +702,7 @@ def test_team_kernel_even_odd_row_split(gpu_lib, monkeypatch):
         "        assert r < 2e-6, (d, b, r)\n"
         "print('ok')\n"
     ) % (os.path.join(ROOT, "fft-implementation-in-c_amd"), os.path.join(ROOT, "tests"))
-    env = dict(os.environ, FFT_HIP_TEAM="2", FFT_HIP_TEAM_ASPLIT="1")  # read once per process: a fresh one
+    env = dict(os.environ, FFT_HIP_TEAM="2", FFT_HIP_TEAM_ASPLIT="1",  # read once per process: a fresh one
+               FFT_LIB_PATH=os.path.join(ROOT, "fft-implementation-in-c_amd", "libfft_mi355x_exp.so"))
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
