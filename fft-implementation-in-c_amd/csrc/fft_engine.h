@@ -53,6 +53,22 @@ struct EnginePolicy {
     long long chunk_mb = 0;    // FFT_HIP_CHUNK_MB: > 0 overrides the multi-pass launch-group size
 };
 
+// Element-wise work fused into the first pass's load and the last pass's store of one execute (fftk::TileHooks).
+// Pitches are in elements; 0 = the plan's n.  Tables live in device memory; pre_tab must be readable up to the next
+// multiple of 16 bytes past n_in (the planner pads its own tables).
+template <typename T>
+struct ExecHooks {
+    const fftk::cpx<T>* pre_tab = nullptr;
+    int pre_mode = fftk::HOOK_NONE;
+    long long n_in = 0;        // valid input samples per transform (0: n); the rest reads as zero
+    long long in_pitch = 0;
+    const fftk::cpx<T>* post_tab = nullptr;
+    long long post_tab_b = 0;  // per-transform pitch of post_tab (0: shared)
+    int post_mode = fftk::HOOK_NONE;
+    long long n_out = 0;       // outputs stored per transform (0: n)
+    long long out_pitch = 0;
+};
+
 enum Algo { ALGO_AUTO = 0, ALGO_RADIX2 = 1, ALGO_RADIX4 = 2, ALGO_SPLIT_RADIX = 3, ALGO_RADIX2_GLOBAL = 4, ALGO_BLUESTEIN = 5, ALGO_RADIX2_SHFL = 6 };
 
 struct PassDesc {
@@ -666,6 +682,47 @@ class Pow2Plan {
         return true;
     }
 
+    // The COLUMN transforms of a row-major rows x cols matrix (2D transforms; reference model: the column loop of
+    // applications/image_fft.c:43-60, there an extract / transform / put-back per column): one in-place column pass of the
+    // four-step engine -- cols-strided sub-transforms of length rows, `cols` of them per matrix, no inter-pass twiddle.
+    // Needs rows = 2^log2rows to fit one LDS tile and cols to be a multiple of the 16-byte lane access; false otherwise
+    // (the caller then goes through a transpose).  execute(in, out, n_matrices, inverse) transforms whole matrices.
+    bool build_columns(RT* runtime, int log2rows, int cols, int n_matrices) {
+        rt = runtime;
+        log2n = log2rows;
+        max_batch = n_matrices;
+        algo = ALGO_SPLIT_RADIX;
+        if (log2rows < 1 || cols < V || (cols % V) != 0) return false;
+        PassDesc a;
+        a.log2L = log2rows; a.E = tile_E(1ll << log2rows, 1); a.loadm = fftk::LOAD_CCONTIG; a.storem = fftk::STORE_CCONTIG;
+        a.twiddle = 0; a.log2Ntw = 0;
+        const long long per_matrix = (long long)cols << log2rows;
+        a.in_b = per_matrix; a.in_c = 1; a.in_l = cols; a.out_b = per_matrix; a.out_c = 1; a.out_k = cols;
+        a.n_cols = cols;
+        long long ext = 1;
+        while (ext < cols) ext <<= 1;
+        if (!choose_tile(a, ext, rt->max_lds_bytes())) return false;
+        a.n_ct = (int)((cols + (1ll << a.log2C) - 1) >> a.log2C);
+        a.fam = fftk::FAM_R4;
+        passes.assign(1, a);
+        PassDesc& p = passes[0];
+        layout_tables(p);
+        std::vector<cpx<T>> blob((size_t)p.tables_elems), part;
+        for (auto& z : blob) { z.re = (T)1; z.im = (T)0; }
+        const long long L = 1ll << p.log2L;
+        make_twiddle_table<T>(part, L, 1ll << p.sa_bits, 1);
+        std::copy(part.begin(), part.end(), blob.begin());
+        make_twiddle_table<T>(part, L, 1ll << (p.log2L - p.sa_bits), 1ll << p.sa_bits);
+        std::copy(part.begin(), part.end(), blob.begin() + p.o_sb);
+        cpx<T>* d = (cpx<T>*)rt->dmalloc(blob.size() * SZ);
+        if (!d) return false;
+        rt->h2d(d, blob.data(), blob.size() * SZ);
+        pass_tables.push_back(d);
+        chunk = n_matrices;
+        ok = true;
+        return true;
+    }
+
     template <int E, int FAM, int LM, int SM, bool TW>
     void launch_one(const fftk::TileParams<T>& tp, long long grid, const PassDesc& p) {
         if (E == 8 && p.log2H == 1) launch_one_h<E, (E == 8 ? 2 : 1), FAM, LM, SM, TW>(tp, grid, p);
@@ -740,7 +797,7 @@ class Pow2Plan {
         }
     }
 
-    void launch_pass(size_t ipass, const cpx<T>* in, cpx<T>* out, int nb, bool inverse, T scale) {
+    fftk::TileParams<T> pass_params(size_t ipass, const cpx<T>* in, cpx<T>* out, int nb, bool inverse, T scale) {
         const PassDesc& p = passes[ipass];
         fftk::TileParams<T> tp;
         memset(&tp, 0, sizeof(tp));
@@ -792,12 +849,96 @@ class Pow2Plan {
             tp.n_cols = p.n_cols;
             tp.n_tiles = (long long)nb * p.n_b_per_transform * p.n_o * p.n_ct;
         }
+        return tp;
+    }
+
+    void launch_pass(size_t ipass, const cpx<T>* in, cpx<T>* out, int nb, bool inverse, T scale) {
+        const PassDesc& p = passes[ipass];
+        const fftk::TileParams<T> tp = pass_params(ipass, in, out, nb, inverse, scale);
         static const int nonpersistent = FFT_EXP_ENV("FFT_HIP_NONPERSISTENT") ? 1 : 0;
         long long grid = nonpersistent ? tp.n_tiles : -1;  // -1: launch_one sizes the persistent grid from the occupancy query
         switch (p.fam) {
             case fftk::FAM_R2: launch_fam<fftk::FAM_R2, 1>(tp, grid, p); break;
             case fftk::FAM_R4: launch_fam<fftk::FAM_R4, 1>(tp, grid, p); break;
             default: launch_fam<fftk::FAM_SR16, 1>(tp, grid, p); break;
+        }
+    }
+
+    // ---- fused element-wise work (fftk::TileHooks): three HOOK instantiations cover AUTO's plans -- the single-pass
+    // rows kernel, the first (column) pass and the last (transposing row) pass
+    static int hook_kind(const PassDesc& p) {
+        using namespace fftk;
+        if (p.log2H != 0) return 0;
+        if (p.loadm == LOAD_LCONTIG && p.storem == STORE_LCONTIG && p.E == 4 && p.fam == FAM_R4 && !p.twiddle) return 1;
+        if (p.loadm == LOAD_CCONTIG && p.storem == STORE_CCONTIG && p.E == 8 && p.fam == FAM_R4 && p.twiddle) return 2;
+        if (p.loadm == LOAD_LCONTIG && p.storem == STORE_CCONTIG && p.E == 8 && p.fam == FAM_SR16 && !p.twiddle) return 3;
+        return 0;
+    }
+    bool hook_capable() const {
+        if (!ok || passes.empty() || log2n == 0) return false;
+        if (algo == ALGO_RADIX2_GLOBAL || algo == ALGO_RADIX2_SHFL) return false;
+        if (passes.size() == 1) return hook_kind(passes[0]) == 1;
+        return hook_kind(passes.front()) == 2 && hook_kind(passes.back()) == 3;
+    }
+
+    // side: bit 0 this launch carries the load side of `h`, bit 1 the store side
+    void launch_pass_hooked(size_t ipass, const cpx<T>* in, cpx<T>* out, int nb, bool inverse, T scale, const ExecHooks<T>& h, int side,
+                            long long tab_off) {
+        using namespace fftk;
+        const PassDesc& p = passes[ipass];
+        TileParams<T> tp = pass_params(ipass, in, out, nb, inverse, scale);
+        const long long n = 1ll << log2n;
+        TileHooks<T>& k = tp.hk;
+        k.n_in = 0x7fffffff; k.n_out = 0x7fffffff; k.in_vec_ok = 1; k.out_vec_ok = 1;
+        if (side & 1) {
+            const long long pitch = h.in_pitch ? h.in_pitch : n;
+            k.pre_tab = h.pre_tab; k.pre_mode = h.pre_tab ? h.pre_mode : HOOK_NONE;
+            k.n_in = (int)(h.n_in ? h.n_in : n);
+            k.in_vec_ok = (pitch % V) == 0 ? 1 : 0;
+            if (p.n_cols < 0) tp.in_c = pitch; else tp.in_b = pitch;
+        }
+        if (side & 2) {
+            const long long pitch = h.out_pitch ? h.out_pitch : n;
+            k.post_tab = h.post_tab ? h.post_tab + tab_off : nullptr;
+            k.post_tab_b = h.post_tab_b;
+            k.post_mode = (h.post_tab || h.post_mode == HOOK_ABS2) ? h.post_mode : HOOK_NONE;
+            k.n_out = (int)(h.n_out ? h.n_out : n);
+            k.out_vec_ok = (pitch % V) == 0 ? 1 : 0;
+            if (p.n_cols < 0) tp.out_c = pitch; else tp.out_b = pitch;
+        }
+        switch (hook_kind(p)) {
+            // HOOK bits: 1 load side, 2 store side, 4 table values prefetched with the data (fft_kernels.h)
+            case 1: launch_kernel(tile_fft_kernel<T, 4, 1, FAM_R4, LOAD_LCONTIG, STORE_LCONTIG, false, 0, 3>, tp, -1, p); break;
+            case 2: launch_kernel(tile_fft_kernel<T, 8, 1, FAM_R4, LOAD_CCONTIG, STORE_CCONTIG, true, 0, 1 | 4>, tp, -1, p); break;
+            case 3: launch_kernel(tile_fft_kernel<T, 8, 1, FAM_SR16, LOAD_LCONTIG, STORE_CCONTIG, false, 0, 2>, tp, -1, p); break;
+            default: break;
+        }
+    }
+
+    // execute() with fused element-wise ends; requires hook_capable().  Never the team kernel (it has no hooks).
+    void execute_hooked(const cpx<T>* in, cpx<T>* out, int nb, bool inverse, const ExecHooks<T>& h, T extra_scale = (T)1) {
+        const long long n = 1ll << log2n;
+        const T scale = (T)((inverse ? 1.0L / (long double)n : 1.0L) * (long double)extra_scale);
+        const long long ip = h.in_pitch ? h.in_pitch : n, op = h.out_pitch ? h.out_pitch : n;
+        run_if = nullptr;
+        if (passes.size() == 1) {
+            launch_pass_hooked(0, in, out, nb, inverse, scale, h, 3, 0);
+            rt->mark(0);
+            return;
+        }
+        const size_t last = passes.size() - 1;
+        for (int b0 = 0; b0 < nb; b0 += chunk) {
+            const int cb = (nb - b0) < chunk ? (nb - b0) : chunk;
+            const cpx<T>* src = in + (size_t)b0 * (size_t)ip;
+            cpx<T>* dst = out + (size_t)b0 * (size_t)op;
+            launch_pass_hooked(0, src, scratch, cb, inverse, (T)1, h, 1, 0);
+            rt->mark(0);
+            if (passes.size() == 3) {
+                launch_pass(1, scratch, scratch, cb, inverse, (T)1);
+                rt->mark(1);
+            }
+            launch_pass_hooked(last, scratch, dst, cb, inverse, scale, h, 2, (long long)b0 * h.post_tab_b);
+            rt->mark((int)last);
         }
     }
 
@@ -892,6 +1033,7 @@ class BluesteinPlan {
     cpx<T>* bfft = nullptr;   // m entries
     cpx<T>* work = nullptr;   // max_batch * m
     bool ok = false;
+    bool no_fusion = false;   // tests: run the element-wise steps as kernels of their own
 
     ~BluesteinPlan() {
         if (!rt) return;
@@ -917,36 +1059,52 @@ class BluesteinPlan {
             c[(size_t)k].re = (T)cosl(ang);
             c[(size_t)k].im = (T)sinl(ang);
         }
+        c.push_back(c[0]);  // padding entry (see the allocation)
         for (long long k = 0; k < m; k++) { b[(size_t)k].re = 0; b[(size_t)k].im = 0; }
         for (long long k = 0; k < n; k++) {
             b[(size_t)k] = c[(size_t)k];
             if (k > 0) b[(size_t)(m - k)] = c[(size_t)k];
         }
-        chirp = (cpx<T>*)rt->dmalloc((size_t)n * SZ);
+        chirp = (cpx<T>*)rt->dmalloc((size_t)(n + 1) * SZ);  // + 1: a 16-byte table read of the last fp32 pair stays inside
         bfft = (cpx<T>*)rt->dmalloc((size_t)m * SZ);
         work = (cpx<T>*)rt->dmalloc((size_t)batch * (size_t)m * SZ);
         if (!chirp || !bfft || !work) return false;
-        rt->h2d(chirp, c.data(), (size_t)n * SZ);
+        rt->h2d(chirp, c.data(), (size_t)(n + 1) * SZ);
         rt->h2d(bfft, b.data(), (size_t)m * SZ);
         core.execute(bfft, bfft, 1, false);
         ok = true;
         return true;
     }
 
+    // FFT_m(x conj(chirp), zero padded) * B -> inverse FFT_m -> * conj(chirp), first n.  With hook-capable passes the
+    // three element-wise steps ride on the FFT passes (modulate + zero fill in the forward transform's first load,
+    // the product with B in its last store, demodulate + truncate + 1/n in the inverse transform's last store): two
+    // transforms, no HBM round trip of their own; the zero half of the padded input is never read and the discarded
+    // half of the result never written.
     void execute(const cpx<T>* in, cpx<T>* out, int nb) {
         const long long m = 1ll << log2m;
+        const T scale = dir > 0 ? (T)(1.0L / (long double)n) : (T)1;
+        if (core.hook_capable() && !no_fusion) {
+            ExecHooks<T> f;
+            f.pre_tab = chirp; f.pre_mode = fftk::HOOK_MUL_CONJ; f.n_in = n; f.in_pitch = n;
+            f.post_tab = bfft; f.post_mode = fftk::HOOK_MUL;
+            core.execute_hooked(in, work, nb, false, f);
+            ExecHooks<T> g;
+            g.post_tab = chirp; g.post_mode = fftk::HOOK_MUL_CONJ; g.n_out = n; g.out_pitch = n;
+            core.execute_hooked(work, out, nb, true, g, scale);  // the inverse carries the 1/m
+            return;
+        }
         const unsigned per_block = 256 * BLU_PER_THREAD;
         const unsigned bpr_m = (unsigned)((m + per_block - 1) / per_block);
         const unsigned bpr_n = (unsigned)(((long long)n + per_block - 1) / per_block);
-        rt->launch(fftk::blu_modulate_kernel<T>, (long long)bpr_m * nb, 256, (size_t)0, in, (const cpx<T>*)chirp, work, n,
-                   log2m, bpr_m);
+        rt->launch(fftk::pad_mul_kernel<T>, (long long)bpr_m * nb, 256, (size_t)0, in, (long long)n, n, (const cpx<T>*)chirp,
+                   (int)fftk::HOOK_MUL_CONJ, work, (int)m, bpr_m);
         core.execute(work, work, nb, false);
-        rt->launch(fftk::blu_pointwise_kernel<T>, (long long)bpr_m * nb, 256, (size_t)0, work, (const cpx<T>*)bfft, log2m,
-                   bpr_m);
+        rt->launch(fftk::mul_store_kernel<T>, (long long)bpr_m * nb, 256, (size_t)0, (const cpx<T>*)work, m, (const cpx<T>*)bfft, 0ll,
+                   (int)fftk::HOOK_MUL, work, m, (int)m, (T)1, bpr_m);
         core.execute(work, work, nb, true);  // carries the 1/m
-        const T scale = dir > 0 ? (T)(1.0L / (long double)n) : (T)1;
-        rt->launch(fftk::blu_demodulate_kernel<T>, (long long)bpr_n * nb, 256, (size_t)0, (const cpx<T>*)work,
-                   (const cpx<T>*)chirp, out, n, log2m, bpr_n, scale);
+        rt->launch(fftk::mul_store_kernel<T>, (long long)bpr_n * nb, 256, (size_t)0, (const cpx<T>*)work, m, (const cpx<T>*)chirp, 0ll,
+                   (int)fftk::HOOK_MUL_CONJ, out, (long long)n, n, scale, bpr_n);
     }
 };
 

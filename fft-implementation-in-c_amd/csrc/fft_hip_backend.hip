@@ -33,6 +33,7 @@ FFT_ROWS_LIST(FFT_EXTERN)
 }  // namespace fftk
 
 #include "fft_engine.h"
+#include "fft_plans_ext.h"
 
 #define HIP_TRY(call, fail)                                                                          \
     do {                                                                                             \
@@ -44,6 +45,9 @@ FFT_ROWS_LIST(FFT_EXTERN)
     } while (0)
 
 namespace {
+
+// resource counters (fft_gpu_debug_counters_hip): what a "cheap" repeated call must not move
+long long g_count_allocs = 0, g_count_streams = 0;
 
 // ---------------------------------------------------------------- runtime policy
 struct HipRT {
@@ -61,6 +65,7 @@ struct HipRT {
             (void)hipGetLastError();
             return nullptr;
         }
+        __atomic_fetch_add(&g_count_allocs, 1ll, __ATOMIC_RELAXED);
         return p;
     }
     void dfree(void* p) {
@@ -229,8 +234,18 @@ struct fft_gpu_plan {
     ffteng::Pow2Plan<double, HipRT>* p64 = nullptr;
     ffteng::BluesteinPlan<float, HipRT>* b32 = nullptr;
     ffteng::BluesteinPlan<double, HipRT>* b64 = nullptr;
+    // plans built on the batched engine (fft_plans_ext.h); kind says which member is live
+    int kind = 0;  // 0 complex 1D, 1 complex 2D (n = rows * cols, batch = matrices), 2 r2c, 3 c2r, 4 fused consumer
+    int rows = 0, cols = 0;
+    ffteng::Plan2D<float, HipRT>* d32 = nullptr;
+    ffteng::Plan2D<double, HipRT>* d64 = nullptr;
+    ffteng::RealPlan<float, HipRT>* r32 = nullptr;
+    ffteng::RealPlan<double, HipRT>* r64 = nullptr;
+    ffteng::FusedPlan<float, HipRT>* f32 = nullptr;
+    ffteng::FusedPlan<double, HipRT>* f64 = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
+enum { PLAN_C2C = 0, PLAN_2D = 1, PLAN_R2C = 2, PLAN_C2R = 3, PLAN_FUSED = 4 };
 
 namespace {
 
@@ -294,11 +309,30 @@ int plan_team_status(fft_gpu_plan* p) {
     return -1;
 }
 
+// bytes one execute reads from its input and writes to its output buffer
+void plan_io_bytes(const fft_gpu_plan* p, size_t* in_bytes, size_t* out_bytes) {
+    const size_t csz = p->prec == FFT_PREC_F32 ? sizeof(complex32_t) : sizeof(complex_t);
+    const size_t rsz = csz / 2;
+    const size_t nb = (size_t)p->batch, n = (size_t)p->n;
+    switch (p->kind) {
+        case PLAN_R2C: *in_bytes = nb * n * rsz; *out_bytes = nb * (n / 2 + 1) * csz; break;
+        case PLAN_C2R: *in_bytes = nb * (n / 2 + 1) * csz; *out_bytes = nb * n * rsz; break;
+        default: *in_bytes = *out_bytes = nb * n * csz; break;
+    }
+}
+
 int plan_enqueue(fft_gpu_plan* p, const void* d_in, void* d_out) {
     if (!p || !d_in || !d_out) return -1;
     DeviceGuard guard(p->device);
     const bool inv = p->dir > 0;
-    if (p->p32) p->p32->execute((const fftk::cpx<float>*)d_in, (fftk::cpx<float>*)d_out, p->batch, inv);
+    if (p->d32) p->d32->execute((const fftk::cpx<float>*)d_in, (fftk::cpx<float>*)d_out, p->batch);
+    else if (p->d64) p->d64->execute((const fftk::cpx<double>*)d_in, (fftk::cpx<double>*)d_out, p->batch);
+    else if (p->r32 && p->kind == PLAN_R2C) p->r32->execute_r2c((const float*)d_in, (fftk::cpx<float>*)d_out, p->batch);
+    else if (p->r64 && p->kind == PLAN_R2C) p->r64->execute_r2c((const double*)d_in, (fftk::cpx<double>*)d_out, p->batch);
+    else if (p->r32) p->r32->execute_c2r((const fftk::cpx<float>*)d_in, (float*)d_out, p->batch);
+    else if (p->r64) p->r64->execute_c2r((const fftk::cpx<double>*)d_in, (double*)d_out, p->batch);
+    else if (p->f32 || p->f64) return -1;  // fused consumers take two inputs: fft_gpu_execute_fused_hip
+    else if (p->p32) p->p32->execute((const fftk::cpx<float>*)d_in, (fftk::cpx<float>*)d_out, p->batch, inv);
     else if (p->p64) p->p64->execute((const fftk::cpx<double>*)d_in, (fftk::cpx<double>*)d_out, p->batch, inv);
     else if (p->b32) p->b32->execute((const fftk::cpx<float>*)d_in, (fftk::cpx<float>*)d_out, p->batch);
     else if (p->b64) p->b64->execute((const fftk::cpx<double>*)d_in, (fftk::cpx<double>*)d_out, p->batch);
@@ -377,6 +411,7 @@ fft_gpu_memory_t fft_gpu_alloc_bytes_hip(size_t bytes) {
         free(mem);
         return NULL;
     }
+    __atomic_fetch_add(&g_count_allocs, 1ll, __ATOMIC_RELAXED);
     mem->device_ptr = p;
     mem->size = bytes;
     mem->device = dev;
@@ -502,11 +537,142 @@ void fft_gpu_destroy_plan_hip(fft_gpu_plan_t p) {
         delete p->p64;
         delete p->b32;
         delete p->b64;
+        delete p->d32;
+        delete p->d64;
+        delete p->r32;
+        delete p->r64;
+        delete p->f32;
+        delete p->f64;
         if (p->ev0) (void)hipEventDestroy(p->ev0);
         if (p->ev1) (void)hipEventDestroy(p->ev1);
         if (p->own_stream) (void)hipStreamDestroy(p->own_stream);
     }
     delete p;
+}
+
+// ---- plans built on the batched engine (fft_plans_ext.h): common shell
+static fft_gpu_plan* new_plan_shell(int n, int batch, int dir, fft_precision_t prec, int kind) {
+    if (!g_initialized) {
+        fprintf(stderr, "fft_hip: plan requested before fft_gpu_init\n");
+        return NULL;
+    }
+    if (prec != FFT_PREC_F32 && prec != FFT_PREC_F64) return NULL;
+    fft_gpu_plan* p = new (std::nothrow) fft_gpu_plan();
+    if (!p) return NULL;
+    p->n = n; p->batch = batch; p->dir = dir < 0 ? -1 : 1; p->prec = (int)prec; p->kind = kind; p->pow2 = false;
+    int dev = g_device;
+    (void)hipGetDevice(&dev);
+    p->device = dev;
+    const DeviceInfo* di = device_info(dev);
+    if (!di || hipStreamCreateWithFlags(&p->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        (void)hipGetLastError();
+        delete p;
+        return NULL;
+    }
+    __atomic_fetch_add(&g_count_streams, 1ll, __ATOMIC_RELAXED);
+    p->rt.stream = p->own_stream;
+    p->rt.lds_limit = di->lds_limit;
+    p->rt.cus = di->cus;
+    p->rt.gfx950 = di->gfx950;
+    p->rt.policy = g_policy;
+    return p;
+}
+static fft_gpu_plan_t finish_plan(fft_gpu_plan* p, bool ok, const char* what) {
+    if (ok) ok = (hipStreamSynchronize(p->own_stream) == hipSuccess);
+    if (!ok) {
+        fprintf(stderr, "fft_hip: could not build a %s plan\n", what);
+        (void)hipGetLastError();
+        fft_gpu_destroy_plan_hip(p);
+        return NULL;
+    }
+    return p;
+}
+
+// 2D complex transform of `n_matrices` row-major rows x cols matrices (replaces the stub gpu/fft_gpu.c:377-385)
+fft_gpu_plan_t fft_gpu_plan_2d_ex_hip(int rows, int cols, int n_matrices, fft_direction dir, fft_precision_t prec) {
+    if (rows <= 0 || cols <= 0 || n_matrices <= 0 || (long long)rows * cols > (1ll << 30)) {
+        fprintf(stderr, "fft_hip: invalid 2D plan arguments (rows=%d cols=%d matrices=%d)\n", rows, cols, n_matrices);
+        return NULL;
+    }
+    fft_gpu_plan* p = new_plan_shell(rows * cols, n_matrices, (int)dir, prec, PLAN_2D);
+    if (!p) return NULL;
+    p->rows = rows; p->cols = cols;
+    bool ok;
+    if (prec == FFT_PREC_F32) {
+        p->d32 = new (std::nothrow) ffteng::Plan2D<float, HipRT>();
+        ok = p->d32 && p->d32->build(&p->rt, rows, cols, p->dir, n_matrices);
+    } else {
+        p->d64 = new (std::nothrow) ffteng::Plan2D<double, HipRT>();
+        ok = p->d64 && p->d64->build(&p->rt, rows, cols, p->dir, n_matrices);
+    }
+    return finish_plan(p, ok, "2D");
+}
+fft_gpu_plan_t fft_gpu_plan_2d_hip(int rows, int cols, fft_direction dir) { return fft_gpu_plan_2d_ex_hip(rows, cols, 1, dir, FFT_PREC_F64); }
+
+// real-input forward / real-output inverse 1D transforms, n/2 + 1 bins (reference stubs algorithms/auto/fft_auto.c:391-409)
+static fft_gpu_plan_t plan_real(int n, int batch, fft_precision_t prec, bool r2c) {
+    if (n <= 0 || batch <= 0) {
+        fprintf(stderr, "fft_hip: invalid real-transform plan arguments (n=%d batch=%d)\n", n, batch);
+        return NULL;
+    }
+    fft_gpu_plan* p = new_plan_shell(n, batch, r2c ? -1 : 1, prec, r2c ? PLAN_R2C : PLAN_C2R);
+    if (!p) return NULL;
+    bool ok;
+    if (prec == FFT_PREC_F32) {
+        p->r32 = new (std::nothrow) ffteng::RealPlan<float, HipRT>();
+        ok = p->r32 && p->r32->build(&p->rt, n, r2c, batch);
+    } else {
+        p->r64 = new (std::nothrow) ffteng::RealPlan<double, HipRT>();
+        ok = p->r64 && p->r64->build(&p->rt, n, r2c, batch);
+    }
+    return finish_plan(p, ok, r2c ? "r2c" : "c2r");
+}
+fft_gpu_plan_t fft_gpu_plan_r2c_1d_hip(int n, int batch, fft_precision_t prec) { return plan_real(n, batch, prec, true); }
+fft_gpu_plan_t fft_gpu_plan_c2r_1d_hip(int n, int batch, fft_precision_t prec) { return plan_real(n, batch, prec, false); }
+
+// fused consumers (fft_plans_ext.h FusedPlan); h_host: the nh kernel samples of a convolution (host memory, element
+// type of `prec`), ignored otherwise
+fft_gpu_plan_t fft_gpu_plan_fused_hip(fft_gpu_fused_t kind, int nx, int nh, const void* h_host, int batch, fft_precision_t prec) {
+    if (nx <= 0 || batch <= 0 || (int)kind < 0 || (int)kind > 4) {
+        fprintf(stderr, "fft_hip: invalid fused plan arguments (kind=%d nx=%d batch=%d)\n", (int)kind, nx, batch);
+        return NULL;
+    }
+    fft_gpu_plan* p = new_plan_shell(nx, batch, -1, prec, PLAN_FUSED);
+    if (!p) return NULL;
+    bool ok;
+    if (prec == FFT_PREC_F32) {
+        p->f32 = new (std::nothrow) ffteng::FusedPlan<float, HipRT>();
+        ok = p->f32 && p->f32->build(&p->rt, (int)kind, nx, nh, (const fftk::cpx<float>*)h_host, batch);
+    } else {
+        p->f64 = new (std::nothrow) ffteng::FusedPlan<double, HipRT>();
+        ok = p->f64 && p->f64->build(&p->rt, (int)kind, nx, nh, (const fftk::cpx<double>*)h_host, batch);
+    }
+    return finish_plan(p, ok, "fused");
+}
+// elements per output row of a fused plan (complex values; FFT_GPU_FUSED_PSD: real values)
+int fft_gpu_fused_out_len_hip(fft_gpu_plan_t p) {
+    if (!p) return -1;
+    if (p->f32) return p->f32->out_len();
+    if (p->f64) return p->f64->out_len();
+    return -1;
+}
+// async on the plan's stream.  d_x: [batch][nx]; d_y: second signal (XCORR) or NULL; d_out: [batch][out_len]
+int fft_gpu_execute_fused_hip(fft_gpu_plan_t p, const void* d_x, const void* d_y, void* d_out, double sample_rate) {
+    if (!p || !d_x || !d_out || (!p->f32 && !p->f64)) return -1;
+    DeviceGuard guard(p->device);
+    if (p->f32) {
+        if (p->f32->kind == ffteng::FUSED_XCORR && !d_y) return -1;
+        p->f32->execute((const fftk::cpx<float>*)d_x, (const fftk::cpx<float>*)d_y, d_out, p->batch, (float)sample_rate);
+    } else {
+        if (p->f64->kind == ffteng::FUSED_XCORR && !d_y) return -1;
+        p->f64->execute((const fftk::cpx<double>*)d_x, (const fftk::cpx<double>*)d_y, d_out, p->batch, sample_rate);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        fprintf(stderr, "fft_hip: kernel launch failed: %s\n", hipGetErrorString(e));
+        return -1;
+    }
+    return 0;
 }
 
 int fft_gpu_plan_set_stream_hip(fft_gpu_plan_t p, void* hip_stream) {
@@ -553,6 +719,66 @@ int fft_gpu_set_policy_hip(int team_mode, int team_min_batch, int chunk_mb) {
     return 0;
 }
 
+int fft_gpu_host_register_hip(void* host_ptr, size_t bytes) {
+    if (!host_ptr || !bytes || !g_initialized) return -1;
+    if (hipHostRegister(host_ptr, bytes, hipHostRegisterDefault) != hipSuccess) {
+        (void)hipGetLastError();  // already registered, or not registrable: copies simply stay pageable
+        return -1;
+    }
+    return 0;
+}
+int fft_gpu_host_unregister_hip(void* host_ptr) {
+    if (!host_ptr) return -1;
+    if (hipHostUnregister(host_ptr) != hipSuccess) {
+        (void)hipGetLastError();
+        return -1;
+    }
+    return 0;
+}
+void fft_gpu_debug_counters_hip(long long* device_allocations, long long* streams_created) {
+    if (device_allocations) *device_allocations = __atomic_load_n(&g_count_allocs, __ATOMIC_RELAXED);
+    if (streams_created) *streams_created = __atomic_load_n(&g_count_streams, __ATOMIC_RELAXED);
+}
+
+// FFT_MEASURE at the device level (reference TODO algorithms/auto/fft_auto.c:232-235): instead of the static table of
+// sizes and batch crossover (HipRT::team_default_on, TeamDesc::min_batch) time THIS plan's two schedules -- the team
+// kernel and the multi-pass plan -- on scratch buffers of its own size and keep the faster.
+int fft_gpu_plan_measure_hip(fft_gpu_plan_t p, int iters) {
+    if (!p || iters <= 0) return -1;
+    DeviceGuard guard(p->device);
+    auto measure = [&](auto* core) -> int {
+        if (!core || !core->team.tables) return 0;  // one schedule only: nothing to choose
+        size_t in_b = 0, out_b = 0;
+        plan_io_bytes(p, &in_b, &out_b);
+        void* buf = p->rt.dmalloc(in_b);
+        if (!buf) return -1;
+        (void)hipMemsetAsync(buf, 0, in_b, p->rt.stream);
+        const int saved_min = core->team.min_batch;
+        float ms[2] = {0.f, 0.f};
+        int rc = 0;
+        for (int which = 0; which < 2 && rc == 0; which++) {  // 0 multi-pass, 1 team kernel
+            core->team.ok = which == 1;
+            core->team.min_batch = 1;
+            float warm = 0.f;
+            if (fft_gpu_execute_timed_hip(p, buf, buf, 1, &warm) != 0 || fft_gpu_execute_timed_hip(p, buf, buf, iters, &ms[which]) != 0) rc = -1;
+            if (which == 1 && plan_team_status(p) != (int)fftk::TEAM_STATUS_OK) ms[1] = 1e30f;  // fell back or timed out: not a candidate
+        }
+        core->team.min_batch = saved_min;
+        p->rt.dfree(buf);
+        if (rc != 0) {
+            core->team.ok = true;
+            return -1;
+        }
+        const bool team_wins = ms[1] < ms[0];
+        core->team.ok = team_wins;
+        if (team_wins) core->team.min_batch = 1;  // measured for this plan's batch: the static crossover no longer applies
+        return team_wins ? 1 : 0;
+    };
+    if (p->p32) return measure(p->p32);
+    if (p->p64) return measure(p->p64);
+    return 0;
+}
+
 int fft_gpu_plan_set_option_hip(fft_gpu_plan_t p, fft_gpu_plan_option_t option, int value) {
     if (!p) return -1;
     auto each_core = [&](auto&& f) {
@@ -568,6 +794,12 @@ int fft_gpu_plan_set_option_hip(fft_gpu_plan_t p, fft_gpu_plan_option_t option, 
         case FFT_GPU_OPT_TEAM_ENABLE:
             each_core([&](auto* c) { c->team.ok = value != 0 && c->team.tables != nullptr; });
             return 0;
+        case FFT_GPU_OPT_NO_FUSION:
+            if (p->b32) p->b32->no_fusion = value != 0;
+            if (p->b64) p->b64->no_fusion = value != 0;
+            if (p->f32) p->f32->no_fusion = value != 0;
+            if (p->f64) p->f64->no_fusion = value != 0;
+            return (p->b32 || p->b64 || p->f32 || p->f64) ? 0 : -1;
         default:
             return -1;
     }
@@ -582,9 +814,11 @@ int fft_gpu_plan_team_status_hip(fft_gpu_plan_t p) {
 
 void fft_gpu_execute_hip(fft_gpu_plan_t p, fft_gpu_memory_t in, fft_gpu_memory_t out, fft_direction /*ignored*/) {
     if (!p || !in || !out) return;
-    const size_t need = (size_t)p->n * (size_t)p->batch * (p->prec == FFT_PREC_F32 ? sizeof(complex32_t) : sizeof(complex_t));
-    if (in->size < need || out->size < need) {
-        fprintf(stderr, "fft_hip: execute needs %zu-byte buffers (got in=%zu out=%zu)\n", need, in->size, out->size);
+    size_t need_in = 0, need_out = 0;
+    plan_io_bytes(p, &need_in, &need_out);
+    if (in->size < need_in || out->size < need_out) {
+        fprintf(stderr, "fft_hip: execute needs %zu-byte input and %zu-byte output buffers (got in=%zu out=%zu)\n", need_in, need_out,
+                in->size, out->size);
         return;
     }
     if (plan_enqueue(p, in->device_ptr, out->device_ptr) != 0) return;

@@ -4,7 +4,8 @@
 //                           one-, two- and three-pass (four-step) power-of-two engine
 //   bitrev_kernel           stand-alone bit-reversal permutation (reference radix2_dit.c:70-77)
 //   radix2_dit_stage_kernel one in-place radix-2 DIT stage in HBM (reference radix2_dit.c:84-112)
-//   blu_*_kernel            Bluestein modulate / pointwise / demodulate (reference bluestein.c:107-141)
+//   pad_mul / mul_store     element-wise ends of a transform when they are not fused into a pass (TileHooks):
+//                           Bluestein modulate / pointwise / demodulate (reference bluestein.c:107-141), convolutions
 //
 // None of this is MFMA work: butterflies are 2x2 / 4x4 with per-element
 // twiddles, 6 flop/byte at N = 2^20, i.e. HBM-bound.  What
@@ -50,6 +51,27 @@ enum { FAM_SR16 = 0, FAM_R4 = 1, FAM_R2 = 2 };
 //   [ sa | sb | t0 | t1 | t2 ]
 //   stage twiddle     W_L^m   = sa[m & (2^sa_bits - 1)] * sb[m >> sa_bits]      (sb unused when sa_bits == log2L)
 //   inter-pass twiddle W_Ntw^m = t0[m & ..] * t1[(m >> t0_bits) & ..] * t2[m >> (t0_bits + t1_bits)]
+// Fused element-wise work at the two ends of a transform (kernel instantiations with HOOK = true; the first pass of a
+// plan carries the load side, the last pass the store side, a single-pass plan both).  This is what Bluestein's
+// modulate / zero-pad, pointwise product and demodulate / truncate (reference bluestein.c:107-141), the pointwise
+// product of an FFT convolution (applications/convolution.c:52-60) and a window (applications/power_spectrum.c:5-25)
+// cost when they ride on an FFT pass instead of being HBM round trips of their own.
+//   load : x[idx] = idx < n_in ? in[idx] (* pre_tab[idx] | * conj(pre_tab[idx])) : 0        idx = sample index in the transform
+//   store: out[idx] = X[idx] (* post_tab[b * post_tab_b + idx] | * conj(...) | -> |X[idx]|^2), only for idx < n_out
+// Different row pitches of the user's arrays (Bluestein: n on the outside, m inside) are the ordinary in_b / out_b
+// (in_c / out_c for the single-pass kernel) of TileParams, set by the launcher.
+enum { HOOK_NONE = 0, HOOK_MUL = 1, HOOK_MUL_CONJ = 2, HOOK_ABS2 = 3 };
+template <typename T>
+struct TileHooks {
+    const cpx<T>* pre_tab;
+    const cpx<T>* post_tab;
+    long long post_tab_b;  // elements between the tables of consecutive transforms (0: one table for the whole batch)
+    int n_in;              // valid input samples per transform
+    int n_out;             // outputs stored per transform
+    int pre_mode, post_mode;
+    int in_vec_ok, out_vec_ok;  // 16-byte accesses allowed on the user's side (rows 16-byte aligned: even pitch for fp32)
+};
+
 template <typename T>
 struct TileParams {
     const cpx<T>* in;
@@ -81,6 +103,7 @@ struct TileParams {
     // TEAM_STATUS_NO_TEAMS (1) in the word, i.e. gave up before touching anything
     const unsigned* run_if;
     T scale;      // applied at the store (1/N folded into the last pass)
+    TileHooks<T> hk;  // read only by HOOK = true instantiations
 };
 
 template <int X>
@@ -343,6 +366,9 @@ struct TileCoord {
     const cpx<T>* in;
     cpx<T>* out;
     int c0;
+    long long b;      // transform index (multi-pass tiles; the single-pass kernel's transforms are its columns)
+    long long oidx;   // o * out_o: offset of this tile's outputs inside the transform (hooks)
+    long long iidx;   // o * in_o
 };
 
 template <typename T>
@@ -369,6 +395,9 @@ FFT_DEVICE TileCoord<T> tile_coord(const TileParams<T>& p, long long tile) {
     const unsigned o = rest % (unsigned)p.n_o;
     const long long b = rest / (unsigned)p.n_o;
     tc.c0 = ct << p.log2C;
+    tc.b = b;
+    tc.oidx = (long long)o * p.out_o;
+    tc.iidx = (long long)o * p.in_o;
     long long boff_in = b * p.in_b, boff_out = b * p.out_b;
     if (FFT_ABLATE(p.ablate & 16)) boff_out %= (8 * p.out_b);  // timing experiment only: scratch side wraps into 8 transforms (cache-resident)
     if (FFT_ABLATE(p.ablate & 32)) boff_in %= (8 * p.in_b);
@@ -379,7 +408,10 @@ FFT_DEVICE TileCoord<T> tile_coord(const TileParams<T>& p, long long tile) {
 
 // FIXED != 0 bakes (log2L << 8 | log2C) into the instantiation: every LDS offset becomes an immediate and the
 // stage loop unrolls (fewer address VGPRs, less integer VALU); FIXED == 0 reads both from the parameters.
-template <typename T, int E, int H, int FAM, int LOADM, int STOREM, bool TWIDDLE, int FIXED>
+// HOOK: 0 none; bit 0 the load side of TileHooks is compiled in, bit 1 the store side, bit 2 the load-side table values
+// are prefetched together with the data (+ E * 4 VGPRs per group: the 2-waves-per-SIMD kernels; without it they are read
+// when the data is consumed -- the 4-waves-per-SIMD rows kernel, whose 128-VGPR budget has no room for them)
+template <typename T, int E, int H, int FAM, int LOADM, int STOREM, bool TWIDDLE, int FIXED, int HOOK = 0>
 FFT_KERNEL void FFT_LAUNCH_BOUNDS2((E == 4 ? 1024 : 512), (E == 4 ? FFT_WAVES_PER_SIMD_E4 : FFT_WAVES_PER_SIMD)) tile_fft_kernel(TileParams<T> p) {
     constexpr int V = vec16<T>::V;
     constexpr int log2V = Log2<V>::value;
@@ -433,7 +465,15 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2((E == 4 ? 1024 : 512), (E == 4 ? FFT_WAVES_PE
 #endif
     constexpr int DEPTH = FFT_DEPTH;  // 2 = double-buffered prefetch (+32 VGPRs; needs FFT_FORCE_OPAQUE to stay spill-free)
     vec16<T> nxtbuf[DEPTH][H][E];
-    auto prefetch = [&](long long tile, vec16<T> (&nxt)[H][E]) __attribute__((always_inline)) {
+    constexpr bool HK_LOAD = (HOOK & 1) != 0, HK_STORE = (HOOK & 2) != 0, HK_TABPF = (HOOK & 4) != 0;
+    vec16<T> nxttab[HK_TABPF ? DEPTH : 1][HK_TABPF ? H : 1][HK_TABPF ? E : 1];  // the load-side table values of the same chunks
+    const bool pre_on = HK_LOAD && p.hk.pre_mode != HOOK_NONE;  // wave-uniform
+    // index (inside its transform) of the first sample of lane-load i of group h, and its tile column / row
+    auto load_idx0 = [&](const TileCoord<T>& tc, int h, int i, int r, int j, int tid) __attribute__((always_inline)) -> long long {
+        if (LOADM == LOAD_CCONTIG) return tc.iidx + (long long)(r + ((long long)i << log2TPC)) * p.in_l + tc.c0 + h * CG + V * j;
+        return (long long)(((tid + i * nthreads) & cpr_mask) * V);
+    };
+    auto prefetch = [&](long long tile, vec16<T> (&nxt)[H][E], vec16<T> (&ntab)[HK_TABPF ? H : 1][HK_TABPF ? E : 1]) __attribute__((always_inline)) {
         const TileCoord<T> tc = tile_coord(p, tile);
         int r = r_invariant, j = j_invariant, tid = tid_invariant;
         if (E * H >= 16 || FFT_WAVES_PER_SIMD >= 4 || FFT_FORCE_OPAQUE) {
@@ -459,11 +499,49 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2((E == 4 ? 1024 : 512), (E == 4 ? FFT_WAVES_PE
                     src = tc.in + (long long)t * p.in_c + (long long)(l0 >> p.in_blk_bits) * p.in_blk_stride +
                           (l0 & ((1 << p.in_blk_bits) - 1));
                 }
-                if (live) {
+                if (HK_LOAD) {
+                    // zero padding: samples at or beyond n_in are not read; an fp32 pair that straddles the end, or rows
+                    // that are not 16-byte aligned (odd pitch), are read value by value
+                    const long long idx0 = load_idx0(tc, h, i, r, j, tid);
+                    const int n_in = p.hk.n_in;
+                    FFT_UNROLL
+                    for (int vv = 0; vv < V; vv++) nxt[h][i].c[vv] = mk<T>((T)0, (T)0);
+                    if (live && idx0 < n_in) {
+                        if (p.hk.in_vec_ok && idx0 + V <= n_in) {
+                            nxt[h][i] = *reinterpret_cast<const vec16<T>*>(src);
+                        } else {
+                            FFT_UNROLL
+                            for (int vv = 0; vv < V; vv++)
+                                if (idx0 + vv < n_in) nxt[h][i].c[vv] = src[vv];
+                        }
+                        if (HK_TABPF && pre_on) ntab[HK_TABPF ? h : 0][HK_TABPF ? i : 0] = *reinterpret_cast<const vec16<T>*>(p.hk.pre_tab + idx0);  // table padded to a multiple of V
+                    }
+                } else if (live) {
                     nxt[h][i] = *reinterpret_cast<const vec16<T>*>(src);
                 } else {
                     FFT_UNROLL
                     for (int vv = 0; vv < V; vv++) nxt[h][i].c[vv] = mk<T>((T)0, (T)0);
+                }
+            }
+        }
+    };
+    // load-side product, applied to the landed chunks (zero samples stay zero whatever the stale table register holds)
+    auto apply_pre = [&](vec16<T> (&nxt)[H][E], vec16<T> (&ntab)[HK_TABPF ? H : 1][HK_TABPF ? E : 1], const TileCoord<T>& tc, int r, int j, int tid) __attribute__((always_inline)) {
+        if (!pre_on) return;
+        FFT_UNROLL
+        for (int h = 0; h < H; h++) {
+            FFT_UNROLL
+            for (int i = 0; i < E; i++) {
+                const long long idx0 = load_idx0(tc, h, i, r, j, tid);
+                vec16<T> tv;
+                if (HK_TABPF) tv = ntab[HK_TABPF ? h : 0][HK_TABPF ? i : 0];
+                else if (idx0 < p.hk.n_in) tv = *reinterpret_cast<const vec16<T>*>(p.hk.pre_tab + idx0);
+                FFT_UNROLL
+                for (int vv = 0; vv < V; vv++) {
+                    if (idx0 + vv < p.hk.n_in) {
+                        const cpx<T> w = tv.c[vv];
+                        nxt[h][i].c[vv] = p.hk.pre_mode == HOOK_MUL_CONJ ? cmul_conj(nxt[h][i].c[vv], w) : cmul(nxt[h][i].c[vv], w);
+                    }
                 }
             }
         }
@@ -496,11 +574,11 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2((E == 4 ? 1024 : 512), (E == 4 ? FFT_WAVES_PE
     long long tile0 = FFT_BID;
     FFT_UNROLL
     for (int d = 0; d < DEPTH; d++)
-        if (tile0 + d * tile_step < n_tiles) prefetch(tile0 + d * tile_step, nxtbuf[d]);
+        if (tile0 + d * tile_step < n_tiles) prefetch(tile0 + d * tile_step, nxtbuf[d], nxttab[HK_TABPF ? d : 0]);
     FFT_SYNC();  // tables visible (also drains the first prefetches; steady state uses LDS-only barriers)
 
     // one tile: consume `nxt` (landed), refill it with the tile DEPTH steps ahead, compute, store
-    auto do_tile = [&](long long tile, vec16<T> (&nxt)[H][E]) __attribute__((always_inline)) {
+    auto do_tile = [&](long long tile, vec16<T> (&nxt)[H][E], vec16<T> (&ntab)[HK_TABPF ? H : 1][HK_TABPF ? E : 1]) __attribute__((always_inline)) {
         const long long tile_ahead = tile + DEPTH * tile_step;
         const TileCoord<T> tc = tile_coord(p, tile);
         cpx<T> x[H][E][V];
@@ -515,6 +593,7 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2((E == 4 ? 1024 : 512), (E == 4 ? FFT_WAVES_PE
         }
 
         // ---- consume the landed loads: slot e of group h <- element l = r + TPC*e
+        if (HK_LOAD) apply_pre(nxt, ntab, tc, r, j, tid);
         if (LOADM == LOAD_CCONTIG) {
             FFT_UNROLL
             for (int h = 0; h < H; h++) {
@@ -553,7 +632,7 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2((E == 4 ? 1024 : 512), (E == 4 ? FFT_WAVES_PE
         // budget): issued from inside the last group's stages, at the point where the data registers are dead.
         constexpr bool EARLY = (E <= 8) || (FAM != FAM_SR16);  // radix-2/4 codelets leave room for 64 + 64 data VGPRs
         const bool have_next = tile_ahead < n_tiles;
-        if (EARLY && have_next) prefetch(tile_ahead, nxt);
+        if (EARLY && have_next) prefetch(tile_ahead, nxt, ntab);
 
         if (p.inverse) {  // inverse = forward transform between two re<->im swaps
             FFT_UNROLL
@@ -574,10 +653,10 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2((E == 4 ? 1024 : 512), (E == 4 ? FFT_WAVES_PE
         if (!FFT_ABLATE(p.ablate & 2)) {
             FFT_SYNC_LDS();  // staging image / previous tile's last exchange fully consumed
             stockham_all_stages<T, E, FAM, V, H>(x, smem, group_bytes, tw, r, j, log2J, log2TPC, log2L, [&]() {
-                if (!EARLY && have_next) prefetch(tile_ahead, nxt);
+                if (!EARLY && have_next) prefetch(tile_ahead, nxt, ntab);
             });
         } else if (!EARLY && have_next) {
-            prefetch(tile_ahead, nxt);
+            prefetch(tile_ahead, nxt, ntab);
         }
 
         // ---- the prefetched tile has landed long ago: take the vmcnt wait now, before this tile's stores
@@ -621,7 +700,15 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2((E == 4 ? 1024 : 512), (E == 4 ? FFT_WAVES_PE
         }
 
         // ---- store: slot e holds frequency K = r + TPC*e
+        const bool post_on = HK_STORE && p.hk.post_mode != HOOK_NONE;
+        // store-side product of one value: idx = its index inside the transform, tb = the transform's table
+        auto post_op = [&](cpx<T> v, const cpx<T>* tb, long long idx) __attribute__((always_inline)) -> cpx<T> {
+            if (p.hk.post_mode == HOOK_ABS2) return mk<T>(v.re * v.re + v.im * v.im, (T)0);
+            const cpx<T> w = tb[idx];
+            return p.hk.post_mode == HOOK_MUL_CONJ ? cmul_conj(v, w) : cmul(v, w);
+        };
         if (STOREM == STORE_CCONTIG) {
+            const cpx<T>* tb = HK_STORE ? p.hk.post_tab + tc.b * p.hk.post_tab_b : nullptr;
             FFT_UNROLL
             for (int e = 0; e < E; e++) {
                 const long long K = r + ((long long)e << log2TPC);
@@ -631,7 +718,26 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2((E == 4 ? 1024 : 512), (E == 4 ? FFT_WAVES_PE
                         vec16<T> v;
                         FFT_UNROLL
                         for (int vv = 0; vv < V; vv++) v.c[vv] = x[h][e][vv];
-                        *reinterpret_cast<vec16<T>*>(tc.out + K * p.out_k + h * CG + V * j) = v;
+                        cpx<T>* dst = tc.out + K * p.out_k + h * CG + V * j;
+                        if (HK_STORE) {
+                            const long long idx0 = tc.oidx + K * p.out_k + tc.c0 + h * CG + V * j;
+                            if (idx0 < p.hk.n_out) {
+                                if (post_on) {
+                                    FFT_UNROLL
+                                    for (int vv = 0; vv < V; vv++)
+                                        if (idx0 + vv < p.hk.n_out) v.c[vv] = post_op(v.c[vv], tb, idx0 + vv);
+                                }
+                                if (p.hk.out_vec_ok && idx0 + V <= p.hk.n_out) {
+                                    *reinterpret_cast<vec16<T>*>(dst) = v;
+                                } else {
+                                    FFT_UNROLL
+                                    for (int vv = 0; vv < V; vv++)
+                                        if (idx0 + vv < p.hk.n_out) dst[vv] = v.c[vv];
+                                }
+                            }
+                        } else {
+                            *reinterpret_cast<vec16<T>*>(dst) = v;
+                        }
                     }
                 }
             }
@@ -655,10 +761,30 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2((E == 4 ? 1024 : 512), (E == 4 ? FFT_WAVES_PE
                     const int g = tid + i * nthreads;
                     const int t = h * CG + (g >> log2CPR);
                     const int pos = g & cpr_mask;
-                    if (tc.c0 + t < p.n_cols)
-                        *reinterpret_cast<vec16<T>*>(tc.out + (long long)t * p.out_c + (long long)pos * V) =
-                            *reinterpret_cast<const vec16<T>*>(smem + h * group_bytes + (size_t)(g >> log2CPR) * pitch +
-                                                               (size_t)pos * 16);
+                    if (tc.c0 + t < p.n_cols) {
+                        vec16<T> v = *reinterpret_cast<const vec16<T>*>(smem + h * group_bytes + (size_t)(g >> log2CPR) * pitch + (size_t)pos * 16);
+                        cpx<T>* dst = tc.out + (long long)t * p.out_c + (long long)pos * V;
+                        if (HK_STORE) {  // the single-pass kernel's transforms are its columns: transform index = c0 + t
+                            const long long idx0 = (long long)pos * V;
+                            const cpx<T>* tb = p.hk.post_tab + (long long)(tc.c0 + t) * p.hk.post_tab_b;
+                            if (idx0 < p.hk.n_out) {
+                                if (post_on) {
+                                    FFT_UNROLL
+                                    for (int vv = 0; vv < V; vv++)
+                                        if (idx0 + vv < p.hk.n_out) v.c[vv] = post_op(v.c[vv], tb, idx0 + vv);
+                                }
+                                if (p.hk.out_vec_ok && idx0 + V <= p.hk.n_out) {
+                                    *reinterpret_cast<vec16<T>*>(dst) = v;
+                                } else {
+                                    FFT_UNROLL
+                                    for (int vv = 0; vv < V; vv++)
+                                        if (idx0 + vv < p.hk.n_out) dst[vv] = v.c[vv];
+                                }
+                            }
+                        } else {
+                            *reinterpret_cast<vec16<T>*>(dst) = v;
+                        }
+                    }
                 }
             }
         }
@@ -667,7 +793,7 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2((E == 4 ? 1024 : 512), (E == 4 ? FFT_WAVES_PE
     for (long long tile = tile0; tile < n_tiles; tile += DEPTH * tile_step) {
         FFT_UNROLL
         for (int d = 0; d < DEPTH; d++)
-            if (tile + d * tile_step < n_tiles) do_tile(tile + d * tile_step, nxtbuf[d]);
+            if (tile + d * tile_step < n_tiles) do_tile(tile + d * tile_step, nxtbuf[d], nxttab[HK_TABPF ? d : 0]);
     }
 }
 
@@ -820,63 +946,62 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS(256) scale_copy_kernel(const cpx<T>* in, cpx<T
 }
 
 // ---------------------------------------------------------------------------
-// Bluestein (reference algorithms/core/bluestein.c:107-141).  chirp[k] =
-// exp(-dir * i*pi*k^2/n)... stored as the reference's chirp: exp(i * (-dir) * pi k^2 / n).
-//   modulate:    a[b][k] = x[b][k] * conj(chirp[k]) for k < n, 0 for n <= k < m   (:107-109 + zero fill)
-//   pointwise:   a[b][k] *= B[k],  B = FFT_m(b), b[k] = b[m-k] = chirp[k]        (:116-130)
-//   demodulate:  y[b][k] = a[b][k] * conj(chirp[k]) * scale                      (:139-148)
+// Element-wise ends of a transform as kernels of their own -- the UNFUSED form of fftk::TileHooks, used when a plan's
+// passes have no HOOK instantiation (explicit butterfly family, tiny lengths, the team kernel).  Bluestein (reference
+// algorithms/core/bluestein.c:107-141; chirp[k] = exp(i * (-dir) * pi k^2 / n) as stored by the reference):
+//   modulate + zero fill  a[b][k] = x[b][k] * conj(chirp[k]), k < n; 0, n <= k < m      pad_mul_kernel,   HOOK_MUL_CONJ
+//   pointwise             a[b][k] *= B[k], B = FFT_m(b)                                  mul_store_kernel, HOOK_MUL
+//   demodulate            y[b][k] = a[b][k] * conj(chirp[k]) * scale, k < n              mul_store_kernel, HOOK_MUL_CONJ
+// One workgroup handles 256 * BLU_PER_THREAD consecutive k of ONE transform: block -> (row, k-block) costs a single
+// scalar 32-bit division per workgroup, no per-element 64-bit division.
 // ---------------------------------------------------------------------------
-// One workgroup handles 256 * BLU_PER_THREAD consecutive k of ONE transform: block -> (row, k-block) costs a
-// single scalar 32-bit division per workgroup, no per-element 64-bit division.
 #define BLU_PER_THREAD 4
 
+// out[b][k] = k < n_in ? in[b * in_pitch + k] (op) tab[k] : 0,   k < m   (out rows have pitch m)
 template <typename T>
 FFT_KERNEL void FFT_LAUNCH_BOUNDS(256)
-    blu_modulate_kernel(const cpx<T>* x, const cpx<T>* chirp, cpx<T>* a, int n, int log2m, unsigned blocks_per_row) {
+    pad_mul_kernel(const cpx<T>* in, long long in_pitch, int n_in, const cpx<T>* tab, int mode, cpx<T>* out, int m, unsigned blocks_per_row) {
     const unsigned bid = (unsigned)FFT_BID;
     const unsigned row = bid / blocks_per_row;
     const int k0 = (int)(bid - row * blocks_per_row) * (256 * BLU_PER_THREAD) + FFT_TID;
-    const cpx<T>* xr = x + (long long)row * n;
-    cpx<T>* ar = a + ((long long)row << log2m);
-    const int m = 1 << log2m;
+    const cpx<T>* xr = in + (long long)row * in_pitch;
+    cpx<T>* ar = out + (long long)row * m;
     FFT_UNROLL
     for (int u = 0; u < BLU_PER_THREAD; u++) {
         const int k = k0 + u * 256;
         if (k < m) {
             cpx<T> v = mk<T>((T)0, (T)0);
-            if (k < n) v = cmul_conj(xr[k], chirp[k]);
+            if (k < n_in) {
+                v = xr[k];
+                if (mode == HOOK_MUL) v = cmul(v, tab[k]);
+                else if (mode == HOOK_MUL_CONJ) v = cmul_conj(v, tab[k]);
+            }
             ar[k] = v;
         }
     }
 }
 
+// out[b * out_pitch + k] = (in[b * in_pitch + k] (op) tab[b * tab_b + k]) * scale,   k < n_out;  in == out allowed
 template <typename T>
 FFT_KERNEL void FFT_LAUNCH_BOUNDS(256)
-    blu_pointwise_kernel(cpx<T>* a, const cpx<T>* bfft, int log2m, unsigned blocks_per_row) {
+    mul_store_kernel(const cpx<T>* in, long long in_pitch, const cpx<T>* tab, long long tab_b, int mode, cpx<T>* out, long long out_pitch,
+                     int n_out, T scale, unsigned blocks_per_row) {
     const unsigned bid = (unsigned)FFT_BID;
     const unsigned row = bid / blocks_per_row;
     const int k0 = (int)(bid - row * blocks_per_row) * (256 * BLU_PER_THREAD) + FFT_TID;
-    cpx<T>* ar = a + ((long long)row << log2m);
-    const int m = 1 << log2m;
+    const cpx<T>* ar = in + (long long)row * in_pitch;
+    const cpx<T>* tb = tab + (long long)row * tab_b;
+    cpx<T>* yr = out + (long long)row * out_pitch;
     FFT_UNROLL
     for (int u = 0; u < BLU_PER_THREAD; u++) {
         const int k = k0 + u * 256;
-        if (k < m) ar[k] = cmul(ar[k], bfft[k]);
-    }
-}
-
-template <typename T>
-FFT_KERNEL void FFT_LAUNCH_BOUNDS(256) blu_demodulate_kernel(const cpx<T>* a, const cpx<T>* chirp, cpx<T>* y, int n,
-                                                             int log2m, unsigned blocks_per_row, T scale) {
-    const unsigned bid = (unsigned)FFT_BID;
-    const unsigned row = bid / blocks_per_row;
-    const int k0 = (int)(bid - row * blocks_per_row) * (256 * BLU_PER_THREAD) + FFT_TID;
-    const cpx<T>* ar = a + ((long long)row << log2m);
-    cpx<T>* yr = y + (long long)row * n;
-    FFT_UNROLL
-    for (int u = 0; u < BLU_PER_THREAD; u++) {
-        const int k = k0 + u * 256;
-        if (k < n) yr[k] = cscale(cmul_conj(ar[k], chirp[k]), scale);
+        if (k < n_out) {
+            cpx<T> v = ar[k];
+            if (mode == HOOK_MUL) v = cmul(v, tb[k]);
+            else if (mode == HOOK_MUL_CONJ) v = cmul_conj(v, tb[k]);
+            else if (mode == HOOK_ABS2) v = mk<T>(v.re * v.re + v.im * v.im, (T)0);
+            yr[k] = cscale(v, scale);
+        }
     }
 }
 

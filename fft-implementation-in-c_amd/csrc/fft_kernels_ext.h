@@ -1,0 +1,131 @@
+// fft_kernels_ext.h -- the small kernels around the batched 1D engine that the "next" rows of the scope table need
+// (SURVEY.md 8f): matrix transpose (2D transforms whose column length does not fit one LDS tile), the split /
+// merge steps of real-input transforms, one-sided power spectra.  All HBM-bound element-wise or tiled copies.
+#pragma once
+
+#include "fft_kernels.h"
+
+namespace fftk {
+
+// out[b][c][r] = in[b][r][c]: 32 x 32 tiles through LDS (padded rows: no bank conflicts), coalesced on both sides.
+// grid = batch * tiles_r * tiles_c workgroups of 256 threads (32 x 8).
+template <typename T>
+FFT_KERNEL void FFT_LAUNCH_BOUNDS(256) transpose_kernel(const cpx<T>* in, cpx<T>* out, int rows, int cols, long long n_tiles) {
+    FFT_DYN_SMEM(smem);
+    cpx<T>* tile = reinterpret_cast<cpx<T>*>(smem);  // [32][33]
+    const int tr = (rows + 31) / 32, tc = (cols + 31) / 32;
+    const int tx = FFT_TID & 31, ty = FFT_TID >> 5;
+    for (long long t = FFT_BID; t < n_tiles; t += FFT_NBLOCKS) {
+        const long long b = t / ((long long)tr * tc);
+        const int rem = (int)(t - b * (long long)tr * tc);
+        const int r0 = (rem / tc) * 32, c0 = (rem % tc) * 32;
+        const cpx<T>* src = in + b * (long long)rows * cols;
+        cpx<T>* dst = out + b * (long long)rows * cols;
+        FFT_SYNC();
+        FFT_UNROLL
+        for (int k = 0; k < 4; k++) {
+            const int r = r0 + ty + 8 * k, c = c0 + tx;
+            if (r < rows && c < cols) tile[(ty + 8 * k) * 33 + tx] = src[(long long)r * cols + c];
+        }
+        FFT_SYNC();
+        FFT_UNROLL
+        for (int k = 0; k < 4; k++) {
+            const int c = c0 + ty + 8 * k, r = r0 + tx;
+            if (r < rows && c < cols) dst[(long long)c * rows + r] = tile[tx * 33 + ty + 8 * k];
+        }
+    }
+}
+
+// Real input of even length n = 2 h, transformed as ONE complex transform of length h on z[j] = x[2j] + i x[2j+1]
+// (the real array IS that complex array, no copy).  With Z = FFT_h(z):
+//   E[k] = (Z[k] + conj(Z[h-k])) / 2          spectrum of the even samples
+//   O[k] = (Z[k] - conj(Z[h-k])) / (2i)       spectrum of the odd samples        (Z[h] = Z[0])
+//   X[k] = E[k] + W_n^k O[k],  k = 0 .. h      the n/2 + 1 non-redundant bins (reference include/fft_auto.h:88-96)
+// w[k] = W_n^k = exp(-2 pi i k / n), k <= h, comes from a plan-time table.  z: [batch][h], x_out: [batch][h + 1].
+template <typename T>
+FFT_KERNEL void FFT_LAUNCH_BOUNDS(256) r2c_split_kernel(const cpx<T>* z, cpx<T>* x_out, const cpx<T>* w, int h, long long total) {
+    const long long stride = FFT_NBLOCKS * FFT_NTHREADS;
+    for (long long i = FFT_BID * FFT_NTHREADS + FFT_TID; i < total; i += stride) {
+        const long long b = i / (h + 1);
+        const int k = (int)(i - b * (h + 1));
+        const cpx<T>* zb = z + b * h;
+        const cpx<T> a = zb[k == h ? 0 : k];
+        const cpx<T> c0 = zb[(k == 0 || k == h) ? 0 : h - k];
+        const cpx<T> c = mk<T>(c0.re, -c0.im);                                   // conj(Z[h-k])
+        const cpx<T> e = cscale(cadd(a, c), (T)0.5);
+        const cpx<T> o = mul_neg_i(cscale(csub(a, c), (T)0.5));                  // (a - c) / (2i)
+        x_out[b * (h + 1) + k] = cadd(e, cmul(w[k], o));
+    }
+}
+
+// The inverse of the split: X[0..h] (Hermitian half spectrum of a real signal of even length n = 2h) -> Z[0..h-1] with
+//   E[k] = (X[k] + conj(X[h-k])) / 2,  O[k] = (X[k] - conj(X[h-k])) / 2 * conj(W_n^k),  Z[k] = E[k] + i O[k];
+// the inverse complex transform of length h (scaled by 1/h like every inverse here) then returns the n real samples.
+template <typename T>
+FFT_KERNEL void FFT_LAUNCH_BOUNDS(256) c2r_merge_kernel(const cpx<T>* x_in, cpx<T>* z, const cpx<T>* w, int h, long long total) {
+    const long long stride = FFT_NBLOCKS * FFT_NTHREADS;
+    for (long long i = FFT_BID * FFT_NTHREADS + FFT_TID; i < total; i += stride) {
+        const long long b = i / h;
+        const int k = (int)(i - b * h);
+        const cpx<T>* xb = x_in + b * (h + 1);
+        const cpx<T> a = xb[k];
+        const cpx<T> c0 = xb[h - k];
+        const cpx<T> c = mk<T>(c0.re, -c0.im);
+        const cpx<T> e = cscale(cadd(a, c), (T)0.5);
+        const cpx<T> o = cmul_conj(cscale(csub(a, c), (T)0.5), w[k]);
+        z[b * h + k] = cadd(e, mul_pos_i(o));
+    }
+}
+
+// odd lengths: promote the real samples to complex / keep the real parts (the transform itself is then a plain
+// complex one of length n, Bluestein for a non-power-of-two)
+template <typename T>
+FFT_KERNEL void FFT_LAUNCH_BOUNDS(256) real_to_complex_kernel(const T* x, cpx<T>* z, long long total) {
+    const long long stride = FFT_NBLOCKS * FFT_NTHREADS;
+    for (long long i = FFT_BID * FFT_NTHREADS + FFT_TID; i < total; i += stride) z[i] = mk<T>(x[i], (T)0);
+}
+template <typename T>
+FFT_KERNEL void FFT_LAUNCH_BOUNDS(256) complex_to_real_kernel(const cpx<T>* z, T* x, long long total) {
+    const long long stride = FFT_NBLOCKS * FFT_NTHREADS;
+    for (long long i = FFT_BID * FFT_NTHREADS + FFT_TID; i < total; i += stride) x[i] = z[i].re;
+}
+// rows of `len_in` -> rows of `len_out` <= len_in (keep the first len_out of every row)
+template <typename T>
+FFT_KERNEL void FFT_LAUNCH_BOUNDS(256) copy_rows_kernel(const cpx<T>* in, cpx<T>* out, int len_in, int len_out, long long total_out) {
+    const long long stride = FFT_NBLOCKS * FFT_NTHREADS;
+    for (long long i = FFT_BID * FFT_NTHREADS + FFT_TID; i < total_out; i += stride) {
+        const long long b = i / len_out;
+        out[i] = in[b * len_in + (i - b * len_out)];
+    }
+}
+// Hermitian extension: rows of h + 1 bins -> rows of n bins, X[n - k] = conj(X[k])  (odd-length c2r)
+template <typename T>
+FFT_KERNEL void FFT_LAUNCH_BOUNDS(256) hermitian_extend_kernel(const cpx<T>* half, cpx<T>* full, int n, long long total) {
+    const long long stride = FFT_NBLOCKS * FFT_NTHREADS;
+    const int hb = n / 2 + 1;
+    for (long long i = FFT_BID * FFT_NTHREADS + FFT_TID; i < total; i += stride) {
+        const long long b = i / n;
+        const int k = (int)(i - b * n);
+        cpx<T> v = half[b * hb + (k < hb ? k : n - k)];
+        if (k >= hb) v.im = -v.im;
+        full[i] = v;
+    }
+}
+
+// One-sided power spectral density of a (windowed) spectrum: psd[k] = |X[k]|^2 * scale, doubled for 0 < k < n/2
+// (reference applications/power_spectrum.c:73-80).  X: [batch][n], psd: [batch][n/2 + 1] real.
+template <typename T>
+FFT_KERNEL void FFT_LAUNCH_BOUNDS(256) psd_onesided_kernel(const cpx<T>* X, T* psd, int n, T scale, long long total) {
+    const long long stride = FFT_NBLOCKS * FFT_NTHREADS;
+    const int hb = n / 2 + 1;
+    for (long long i = FFT_BID * FFT_NTHREADS + FFT_TID; i < total; i += stride) {
+        const long long b = i / hb;
+        const int k = (int)(i - b * hb);
+        const cpx<T> v = X[b * n + k];
+        T pw = (v.re * v.re + v.im * v.im) * scale;
+        if (k > 0 && k < n / 2) pw *= (T)2;  // the reference's own condition (integer n / 2)
+        psd[i] = pw;
+    }
+}
+
+}  // namespace fftk

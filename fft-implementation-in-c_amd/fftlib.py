@@ -58,6 +58,13 @@ SIGNATURES = {
     "fft_gpu_plan_info_hip": (_i, [_vp, C.POINTER(PlanInfo)]), "fft_gpu_plan_set_stream_hip": (_i, [_vp, _vp]),
     "fft_gpu_execute_ptr_hip": (_i, [_vp, _vp, _vp]), "fft_gpu_plan_sync_hip": (_i, [_vp]),
     "fft_gpu_plan_set_option_hip": (_i, [_vp, _i, _i]), "fft_gpu_set_policy_hip": (_i, [_i, _i, _i]),
+    "fft_gpu_plan_2d_hip": (_vp, [_i, _i, _i]), "fft_gpu_plan_2d_ex_hip": (_vp, [_i, _i, _i, _i, _i]),
+    "fft_gpu_plan_r2c_1d_hip": (_vp, [_i, _i, _i]), "fft_gpu_plan_c2r_1d_hip": (_vp, [_i, _i, _i]),
+    "fft_gpu_plan_fused_hip": (_vp, [_i, _i, _i, _vp, _i, _i]), "fft_gpu_fused_out_len_hip": (_i, [_vp]),
+    "fft_gpu_execute_fused_hip": (_i, [_vp, _vp, _vp, _vp, C.c_double]),
+    "fft_gpu_host_register_hip": (_i, [_vp, _sz]), "fft_gpu_host_unregister_hip": (_i, [_vp]),
+    "fft_gpu_debug_counters_hip": (None, [C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
+    "fft_gpu_plan_measure_hip": (_i, [_vp, _i]),
     "fft_gpu_plan_team_status_hip": (_i, [_vp]), "fft_gpu_plan_team_trace_hip": (_i, [_vp, _vp, _i]),
     "fft_gpu_execute_timed_hip": (_i, [_vp, _vp, _vp, _i, C.POINTER(C.c_float)]),
     "fft_gpu_dft_1d_batch_hip": (_i, [_vp, _vp, _i, _i, _i, _i]),
@@ -81,7 +88,12 @@ SIGNATURES = {
     "fft_export_wisdom_to_string": (_vp, []), "fft_import_wisdom_from_string": (_i, [C.c_char_p]),
     "fft_get_hardware_capabilities": (C.c_uint, []), "fft_plan_with_nthreads": (None, [_i]),
     "fft_alloc_complex": (_vp, [_sz]), "fft_alloc_real": (_vp, [_sz]), "fft_free": (None, [_vp]),
-    "fft_version": (C.c_char_p, []),
+    "fft_version": (C.c_char_p, []), "fft_plan_measured_algo": (_i, [_vp]), "fft_auto_cleanup": (None, []),
+    # include/fft_apps.h, include/fft_utils.h
+    "fft_convolution_gpu": (_i, [_vp, _i, _vp, _i, _vp]), "circular_convolution_gpu": (_i, [_vp, _vp, _i, _vp]),
+    "compute_periodogram_gpu": (_vp, [_vp, _i, C.c_double]), "autocorrelation_fft_gpu": (_vp, [_vp, _i]),
+    "cross_correlation_fft_gpu": (_vp, [_vp, _vp, _i]),
+    "save_complex_array": (_i, [C.c_char_p, _vp, _i]), "load_complex_array": (_i, [C.c_char_p, C.POINTER(_vp), C.POINTER(_i)]),
     # include/fft_algorithms.h
     "radix2_dit_fft_gpu": (_i, [_vp, _i, _i]), "radix2_fft_gpu": (_i, [_vp, _i, _i]),
     "radix4_fft_gpu": (_i, [_vp, _i, _i]), "split_radix_fft_gpu": (_i, [_vp, _i, _i]),
@@ -122,7 +134,7 @@ def init():
 
 
 EXP_LIB_PATH = os.path.join(HERE, "libfft_mi355x_exp.so")  # -DFFT_EXPERIMENTS build: kernel-variant switches, ablation bits
-OPT_TEAM_FORCE_FALLBACK, OPT_TEAM_ENABLE = 1, 2
+OPT_TEAM_FORCE_FALLBACK, OPT_TEAM_ENABLE, OPT_NO_FUSION = 1, 2, 3
 
 
 def set_policy(team=-1, min_batch=-1, chunk_mb=-1):
@@ -225,6 +237,140 @@ class Plan:
             self.destroy()
         except Exception:
             pass
+
+
+FUSED_KINDS = {"conv": 0, "circ": 1, "autocorr": 2, "xcorr": 3, "psd": 4}
+
+
+class ExtPlan:
+    """2D / r2c / c2r / fused plans (fft_hip.h): a thin owner of the handle; execute with raw device pointers."""
+
+    def __init__(self, handle):
+        self.lib = init()
+        if not handle:
+            raise RuntimeError("plan creation failed")
+        self.handle = handle
+
+    @classmethod
+    def fft2d(cls, rows, cols, n_matrices=1, direction=FFT_FORWARD, dtype=np.complex128):
+        return cls(init().fft_gpu_plan_2d_ex_hip(rows, cols, n_matrices, direction, _prec_of(np.dtype(dtype))))
+
+    @classmethod
+    def r2c(cls, n, batch=1, dtype=np.float64):
+        return cls(init().fft_gpu_plan_r2c_1d_hip(n, batch, PREC_F32 if np.dtype(dtype) == np.float32 else PREC_F64))
+
+    @classmethod
+    def c2r(cls, n, batch=1, dtype=np.float64):
+        return cls(init().fft_gpu_plan_c2r_1d_hip(n, batch, PREC_F32 if np.dtype(dtype) == np.float32 else PREC_F64))
+
+    @classmethod
+    def fused(cls, kind, nx, batch=1, h=None, dtype=np.complex128):
+        dt = np.dtype(dtype)
+        hh = None if h is None else np.ascontiguousarray(np.asarray(h).astype(dt))
+        p = cls(init().fft_gpu_plan_fused_hip(FUSED_KINDS[kind], nx, 0 if hh is None else len(hh),
+                                              None if hh is None else hh.ctypes.data, batch, _prec_of(dt)))
+        p.out_len = p.lib.fft_gpu_fused_out_len_hip(p.handle)
+        return p
+
+    def execute_ptr(self, d_in, d_out):
+        if self.lib.fft_gpu_execute_ptr(self.handle, d_in, d_out) != 0:
+            raise RuntimeError("fft_gpu_execute_ptr failed")
+
+    def set_option(self, option, value):
+        if self.lib.fft_gpu_plan_set_option_hip(self.handle, option, value) != 0:
+            raise RuntimeError("fft_gpu_plan_set_option_hip(%d) failed" % option)
+
+    def execute_fused(self, d_x, d_y, d_out, sample_rate=1.0):
+        if self.lib.fft_gpu_execute_fused_hip(self.handle, d_x, d_y, d_out, sample_rate) != 0:
+            raise RuntimeError("fft_gpu_execute_fused_hip failed")
+
+    def sync(self):
+        return self.lib.fft_gpu_plan_sync(self.handle)
+
+    def timed(self, d_in, d_out, iters):
+        ms = C.c_float()
+        if self.lib.fft_gpu_execute_timed(self.handle, d_in, d_out, iters, C.byref(ms)) != 0:
+            raise RuntimeError("fft_gpu_execute_timed failed")
+        return ms.value
+
+    def destroy(self):
+        if self.handle:
+            self.lib.fft_gpu_destroy_plan(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+def _roundtrip(plan, x, out_shape, out_dtype, y=None, fused=False, fs=1.0):
+    a = DeviceBuffer(x.nbytes)
+    a.upload(x)
+    out = np.empty(out_shape, dtype=out_dtype)
+    o = DeviceBuffer(max(out.nbytes, 16))
+    b = None
+    if y is not None:
+        b = DeviceBuffer(y.nbytes)
+        b.upload(y)
+    if fused:
+        plan.execute_fused(a.ptr, b.ptr if b else None, o.ptr, fs)
+    else:
+        plan.execute_ptr(a.ptr, o.ptr)
+    if plan.sync() != 0:
+        raise RuntimeError("execute failed")
+    res = o.download(out_shape, out_dtype)
+    for buf in (a, o, b):
+        if buf:
+            buf.free()
+    return res
+
+
+def fft2d(x, direction=FFT_FORWARD):
+    """x: [rows, cols] or [matrices, rows, cols] complex -> 2D transform of every matrix."""
+    x = np.ascontiguousarray(x)
+    x3 = x.reshape((-1,) + x.shape[-2:])
+    plan = ExtPlan.fft2d(x3.shape[1], x3.shape[2], x3.shape[0], direction, x3.dtype)
+    y = _roundtrip(plan, x3, x3.shape, x3.dtype)
+    plan.destroy()
+    return y.reshape(x.shape)
+
+
+def rfft(x):
+    """x: [batch, n] float32/float64 -> [batch, n//2 + 1] complex."""
+    x = np.ascontiguousarray(x)
+    batch, n = x.shape
+    cdt = np.complex64 if x.dtype == np.float32 else np.complex128
+    plan = ExtPlan.r2c(n, batch, x.dtype)
+    y = _roundtrip(plan, x, (batch, n // 2 + 1), cdt)
+    plan.destroy()
+    return y
+
+
+def irfft(X, n):
+    """X: [batch, n//2 + 1] complex -> [batch, n] real, scaled by 1/n."""
+    X = np.ascontiguousarray(X)
+    rdt = np.float32 if X.dtype == np.complex64 else np.float64
+    plan = ExtPlan.c2r(n, X.shape[0], rdt)
+    y = _roundtrip(plan, X, (X.shape[0], n), rdt)
+    plan.destroy()
+    return y
+
+
+def fused(kind, x, y=None, h=None, fs=1.0):
+    """Batched fused consumer on host arrays: x [batch, nx] complex (see fft_hip.h fft_gpu_fused_t)."""
+    x = np.ascontiguousarray(x)
+    batch, nx = x.shape
+    plan = ExtPlan.fused(kind, nx, batch, h, x.dtype)
+    if kind == "psd":
+        odt = np.float32 if x.dtype == np.complex64 else np.float64
+    else:
+        odt = x.dtype
+    yy = None if y is None else np.ascontiguousarray(np.asarray(y).astype(x.dtype))
+    res = _roundtrip(plan, x, (batch, plan.out_len), odt, y=yy, fused=True, fs=fs)
+    plan.destroy()
+    return res
 
 
 def fft(x, direction=FFT_FORWARD, algo=ALGO_AUTO, inplace=True):

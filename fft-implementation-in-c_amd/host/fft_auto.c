@@ -11,9 +11,19 @@
  *     there is nothing to fall back to (no device => NULL, with a message);
  *   - the dead O(n) twiddle / bit-reversal precompute (:199-212) is gone;
  *   - fft_execute_dft does not mutate the plan (the reference swaps plan->in/out
- *     and is not re-entrant, :291-301).
+ *     and is not re-entrant, :291-301);
+ *   - FFT_MEASURE and above really measure (the reference's TODO, :232-235): the candidate schedules for this n
+ *     are timed on the device at plan time and the fastest is kept;
+ *   - the borrowed host arrays are page-locked for the plan's lifetime (hipHostRegister), so every execute's
+ *     H2D / D2H runs at pinned-memory speed; FFT_CONSERVE_MEMORY skips that;
+ *   - fft_auto() keeps its plans (the reference builds and destroys a plan per call, :325-333): a small cache
+ *     keyed by (n, direction) holds the device plan, its stream and its device buffer, so a repeated call costs
+ *     H2D + execute + D2H and nothing else (no hipMalloc, no stream, no table upload);
+ *   - fft_plan_r2c_1d / fft_plan_c2r_1d / fft_plan_dft_2d are real (NULL / a use-after-free in the reference,
+ *     :391-415): n/2 + 1 bins, c2r scaled by 1/n, the 2D inverse scaled once by 1/(rows*cols).
  */
 #define _POSIX_C_SOURCE 200809L
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -21,20 +31,28 @@
 #include "../../include/fft_algorithms.h"
 #include "../../include/fft_auto.h"
 #include "../../include/fft_gpu.h"
+#include "../../include/fft_hip.h"
 
 #ifndef FFT_VERSION
 #define FFT_VERSION "2.0.0-mi355x"
 #endif
 
+enum { KIND_C2C = 0, KIND_R2C = 1, KIND_C2R = 2, KIND_2D = 3 };
+
 struct fft_plan {
-    int n;
-    complex_t* in;  /* borrowed */
-    complex_t* out; /* borrowed */
+    int kind;
+    int n;          /* transform length (2D: rows * cols) */
+    int rows, cols; /* 2D */
+    void* in;       /* borrowed: complex_t* or double* by kind */
+    void* out;      /* borrowed */
+    size_t in_bytes, out_bytes;
     fft_direction dir;
     unsigned flags;
     fft_gpu_plan_t gpu_plan; /* owned */
     fft_gpu_memory_t gpu_in; /* owned */
     fft_gpu_memory_t gpu_out; /* owned unless == gpu_in */
+    int pinned_in, pinned_out; /* the borrowed arrays are page-locked by this plan */
+    int measured_algo;         /* FFT_MEASURE: the schedule that won (fft_gpu_algo_t), -1 = not measured */
 };
 
 static int g_num_threads = 0;
@@ -44,34 +62,93 @@ static int ensure_gpu(void) {
     return fft_gpu_init(FFT_GPU_AUTO);
 }
 
+/* FFT_MEASURE (reference TODO fft_auto.c:232-235): time the candidate schedules for a single transform of length n on the
+ * device -- AUTO's pick and the explicit radix-4 / radix-2 families for a power of two -- and keep the fastest plan. */
+static fft_gpu_plan_t measured_plan(int n, fft_direction dir, fft_gpu_memory_t buf, int* winner) {
+    static const fft_gpu_algo_t candidates[3] = {FFT_GPU_ALGO_AUTO, FFT_GPU_ALGO_RADIX4, FFT_GPU_ALGO_RADIX2};
+    const int n_cand = is_power_of_two(n) && n >= 4 ? 3 : 1;
+    fft_gpu_plan_t best = NULL;
+    float best_ms = 0.f;
+    for (int c = 0; c < n_cand; c++) {
+        fft_gpu_plan_t p = fft_gpu_plan_1d_ex(n, 1, dir, FFT_PREC_F64, candidates[c]);
+        if (!p) continue;
+        float ms = 0.f;
+        void* d = fft_gpu_memory_ptr(buf);
+        /* one untimed execute (first-launch costs), then 4 timed ones between HIP events on the plan's stream */
+        if (fft_gpu_execute_timed(p, d, d, 1, &ms) != 0 || fft_gpu_execute_timed(p, d, d, 4, &ms) != 0) {
+            fft_gpu_destroy_plan(p);
+            continue;
+        }
+        if (!best || ms < best_ms) {
+            if (best) fft_gpu_destroy_plan(best);
+            best = p;
+            best_ms = ms;
+            *winner = (int)candidates[c];
+        } else {
+            fft_gpu_destroy_plan(p);
+        }
+    }
+    return best;
+}
+
+static fft_plan_t new_plan(int kind, int n, void* in, void* out, size_t in_bytes, size_t out_bytes, fft_direction dir, unsigned flags) {
+    fft_plan_t plan = (fft_plan_t)calloc(1, sizeof(struct fft_plan));
+    if (!plan) return NULL;
+    plan->kind = kind;
+    plan->n = n;
+    plan->in = in;
+    plan->out = out;
+    plan->in_bytes = in_bytes;
+    plan->out_bytes = out_bytes;
+    plan->dir = dir;
+    plan->flags = flags;
+    plan->measured_algo = -1;
+    return plan;
+}
+
+/* device buffers (one when the transform is in place on equally sized arrays) and page-locking of the borrowed arrays */
+static int plan_buffers(fft_plan_t plan) {
+    plan->gpu_in = fft_gpu_alloc_bytes_hip(plan->in_bytes);
+    plan->gpu_out = (plan->in == plan->out && plan->in_bytes == plan->out_bytes) ? plan->gpu_in : fft_gpu_alloc_bytes_hip(plan->out_bytes);
+    if (!plan->gpu_in || !plan->gpu_out) return -1;
+    if (!(plan->flags & FFT_CONSERVE_MEMORY)) {
+        plan->pinned_in = fft_gpu_host_register_hip(plan->in, plan->in_bytes) == 0;
+        if (plan->out != plan->in) plan->pinned_out = fft_gpu_host_register_hip(plan->out, plan->out_bytes) == 0;
+    }
+    return 0;
+}
+
 fft_plan_t fft_plan_dft_1d(int n, complex_t* in, complex_t* out, int sign, unsigned flags) {
     if (n <= 0 || !in || !out) return NULL;
     if (ensure_gpu() != 0) {
         fprintf(stderr, "fft_plan_dft_1d: no MI355X/HIP device -- this build has no CPU path\n");
         return NULL;
     }
-    fft_plan_t plan = (fft_plan_t)calloc(1, sizeof(struct fft_plan));
+    const size_t bytes = (size_t)n * sizeof(complex_t);
+    fft_plan_t plan = new_plan(KIND_C2C, n, in, out, bytes, bytes, (sign < 0) ? FFT_FORWARD : FFT_INVERSE, flags);
     if (!plan) return NULL;
-    plan->n = n;
-    plan->in = in;
-    plan->out = out;
-    plan->dir = (sign < 0) ? FFT_FORWARD : FFT_INVERSE;
-    plan->flags = flags;
-    plan->gpu_plan = fft_gpu_plan_1d(n, 1, plan->dir);
-    plan->gpu_in = fft_gpu_alloc((size_t)n);
-    plan->gpu_out = (in == out) ? plan->gpu_in : fft_gpu_alloc((size_t)n);
-    if (!plan->gpu_plan || !plan->gpu_in || !plan->gpu_out) {
+    if (plan_buffers(plan) != 0) {
+        fft_destroy_plan(plan);
+        return NULL;
+    }
+    const unsigned effort = flags & 7u; /* FFT_ESTIMATE 0 .. FFT_WISDOM_ONLY 4 (fft_auto.h:17-22) */
+    if (effort >= FFT_MEASURE && effort <= FFT_EXHAUSTIVE) plan->gpu_plan = measured_plan(n, plan->dir, plan->gpu_in, &plan->measured_algo);
+    if (!plan->gpu_plan) plan->gpu_plan = fft_gpu_plan_1d(n, 1, plan->dir);
+    if (!plan->gpu_plan) {
         fft_destroy_plan(plan);
         return NULL;
     }
     return plan;
 }
 
-static void run_plan(fft_plan_t plan, complex_t* in, complex_t* out) {
-    fft_gpu_copy_h2d(plan->gpu_in, in, (size_t)plan->n);
+/* which schedule FFT_MEASURE kept (fft_gpu_algo_t), -1 when the plan was not measured (additive) */
+int fft_plan_measured_algo(fft_plan_t plan) { return plan ? plan->measured_algo : -1; }
+
+static void run_plan(fft_plan_t plan, const void* in, void* out) {
+    if (fft_gpu_copy_h2d_bytes_hip(plan->gpu_in, in, plan->in_bytes) != 0) return;
     /* a plan made for distinct arrays can still be executed in place and vice versa */
     fft_gpu_execute(plan->gpu_plan, plan->gpu_in, plan->gpu_out);
-    fft_gpu_copy_d2h(out, plan->gpu_out, (size_t)plan->n);
+    (void)fft_gpu_copy_d2h_bytes_hip(out, plan->gpu_out, plan->out_bytes);
 }
 
 void fft_execute(fft_plan_t plan) {
@@ -81,6 +158,10 @@ void fft_execute(fft_plan_t plan) {
 
 void fft_execute_dft(fft_plan_t plan, complex_t* in, complex_t* out) {
     if (!plan || !in || !out) return;
+    if (plan->kind != KIND_C2C && plan->kind != KIND_2D) {
+        fprintf(stderr, "fft_execute_dft: complex-to-complex plans only\n");
+        return;
+    }
     run_plan(plan, in, out);
 }
 
@@ -89,15 +170,76 @@ void fft_destroy_plan(fft_plan_t plan) {
     fft_gpu_destroy_plan(plan->gpu_plan);
     if (plan->gpu_out && plan->gpu_out != plan->gpu_in) fft_gpu_free(plan->gpu_out);
     fft_gpu_free(plan->gpu_in);
+    if (plan->pinned_in) (void)fft_gpu_host_unregister_hip(plan->in);
+    if (plan->pinned_out) (void)fft_gpu_host_unregister_hip(plan->out);
     free(plan);
 }
 
+/* ---- fft_auto(): one-shot transforms with kept plans ------------------------------------------------------------ */
+enum { AUTO_CACHE_SLOTS = 8 };
+struct auto_slot {
+    int n;
+    fft_direction dir;
+    fft_gpu_plan_t plan;
+    fft_gpu_memory_t buf;
+    unsigned long last_use;
+};
+static struct auto_slot g_auto[AUTO_CACHE_SLOTS];
+static unsigned long g_auto_clock = 0;
+static pthread_mutex_t g_auto_lock = PTHREAD_MUTEX_INITIALIZER;
+
+/* drop every kept plan (additive; also what a caller does before fft_gpu_cleanup()) */
+void fft_auto_cleanup(void) {
+    pthread_mutex_lock(&g_auto_lock);
+    for (int i = 0; i < AUTO_CACHE_SLOTS; i++) {
+        if (g_auto[i].plan) fft_gpu_destroy_plan(g_auto[i].plan);
+        if (g_auto[i].buf) fft_gpu_free(g_auto[i].buf);
+        memset(&g_auto[i], 0, sizeof(g_auto[i]));
+    }
+    pthread_mutex_unlock(&g_auto_lock);
+}
+
 int fft_auto(complex_t* in, complex_t* out, int n, int sign) {
-    fft_plan_t plan = fft_plan_dft_1d(n, in, out, sign, FFT_ESTIMATE | FFT_PREFER_GPU);
-    if (!plan) return -1;
-    fft_execute(plan);
-    fft_destroy_plan(plan);
-    return 0;
+    if (n <= 0 || !in || !out) return -1;
+    if (ensure_gpu() != 0) {
+        fprintf(stderr, "fft_auto: no MI355X/HIP device -- this build has no CPU path\n");
+        return -1;
+    }
+    const fft_direction dir = (sign < 0) ? FFT_FORWARD : FFT_INVERSE;
+    int rc = -1;
+    pthread_mutex_lock(&g_auto_lock); /* the slot's buffer is in use until the D2H below: one fft_auto at a time */
+    struct auto_slot* s = NULL;
+    struct auto_slot* victim = &g_auto[0];
+    for (int i = 0; i < AUTO_CACHE_SLOTS; i++) {
+        if (g_auto[i].plan && g_auto[i].n == n && g_auto[i].dir == dir) s = &g_auto[i];
+        if (!g_auto[i].plan || g_auto[i].last_use < victim->last_use) {
+            if (!victim->plan && g_auto[i].plan) continue; /* an empty slot beats any used one */
+            victim = &g_auto[i];
+        }
+    }
+    if (!s) {
+        if (victim->plan) fft_gpu_destroy_plan(victim->plan);
+        if (victim->buf) fft_gpu_free(victim->buf);
+        memset(victim, 0, sizeof(*victim));
+        victim->plan = fft_gpu_plan_1d(n, 1, dir);
+        victim->buf = fft_gpu_alloc((size_t)n);
+        if (!victim->plan || !victim->buf) {
+            if (victim->plan) fft_gpu_destroy_plan(victim->plan);
+            if (victim->buf) fft_gpu_free(victim->buf);
+            memset(victim, 0, sizeof(*victim));
+            pthread_mutex_unlock(&g_auto_lock);
+            return -1;
+        }
+        victim->n = n;
+        victim->dir = dir;
+        s = victim;
+    }
+    s->last_use = ++g_auto_clock;
+    fft_gpu_copy_h2d(s->buf, in, (size_t)n);
+    fft_gpu_execute(s->plan, s->buf, s->buf);
+    if (fft_gpu_copy_d2h_bytes_hip(out, s->buf, (size_t)n * sizeof(complex_t)) == 0) rc = 0;
+    pthread_mutex_unlock(&g_auto_lock);
+    return rc;
 }
 
 unsigned fft_get_hardware_capabilities(void) {
@@ -131,18 +273,44 @@ void fft_free(void* p) { free(p); }
 
 const char* fft_version(void) { return FFT_VERSION; }
 
-/* ---- stubs kept as stubs (reference fft_auto.c:391-426); out of scope for this path ---- */
+/* ---- real-input, real-output and 2D plans (NULL / broken in the reference, fft_auto.c:391-415) ---- */
 fft_plan_t fft_plan_r2c_1d(int n, double* in, complex_t* out, unsigned flags) {
-    (void)n; (void)in; (void)out; (void)flags;
-    return NULL;
+    if (n <= 0 || !in || !out || ensure_gpu() != 0) return NULL;
+    fft_plan_t plan = new_plan(KIND_R2C, n, in, out, (size_t)n * sizeof(double), ((size_t)n / 2 + 1) * sizeof(complex_t), FFT_FORWARD,
+                               flags | FFT_REAL_INPUT);
+    if (!plan) return NULL;
+    plan->gpu_plan = fft_gpu_plan_r2c_1d_hip(n, 1, FFT_PREC_F64);
+    if (!plan->gpu_plan || plan_buffers(plan) != 0) {
+        fft_destroy_plan(plan);
+        return NULL;
+    }
+    return plan;
 }
 fft_plan_t fft_plan_c2r_1d(int n, complex_t* in, double* out, unsigned flags) {
-    (void)n; (void)in; (void)out; (void)flags;
-    return NULL;
+    if (n <= 0 || !in || !out || ensure_gpu() != 0) return NULL;
+    fft_plan_t plan = new_plan(KIND_C2R, n, in, out, ((size_t)n / 2 + 1) * sizeof(complex_t), (size_t)n * sizeof(double), FFT_INVERSE,
+                               flags | FFT_REAL_OUTPUT);
+    if (!plan) return NULL;
+    plan->gpu_plan = fft_gpu_plan_c2r_1d_hip(n, 1, FFT_PREC_F64);
+    if (!plan->gpu_plan || plan_buffers(plan) != 0) {
+        fft_destroy_plan(plan);
+        return NULL;
+    }
+    return plan;
 }
 fft_plan_t fft_plan_dft_2d(int rows, int cols, complex_t* in, complex_t* out, int sign, unsigned flags) {
-    (void)rows; (void)cols; (void)in; (void)out; (void)sign; (void)flags;
-    return NULL;
+    if (rows <= 0 || cols <= 0 || (long long)rows * cols > (1ll << 30) || !in || !out || ensure_gpu() != 0) return NULL;
+    const size_t bytes = (size_t)rows * (size_t)cols * sizeof(complex_t);
+    fft_plan_t plan = new_plan(KIND_2D, rows * cols, in, out, bytes, bytes, (sign < 0) ? FFT_FORWARD : FFT_INVERSE, flags);
+    if (!plan) return NULL;
+    plan->rows = rows;
+    plan->cols = cols;
+    plan->gpu_plan = fft_gpu_plan_2d(rows, cols, plan->dir);
+    if (!plan->gpu_plan || plan_buffers(plan) != 0) {
+        fft_destroy_plan(plan);
+        return NULL;
+    }
+    return plan;
 }
 char* fft_export_wisdom_to_string(void) { return strdup("# FFT Wisdom v2.0.0 (mi355x: plans are deterministic, nothing to save)\n"); }
 int fft_import_wisdom_from_string(const char* wisdom) { return wisdom ? 1 : 0; }

@@ -191,13 +191,27 @@ int fft_gpu_device_count(void) { return fft_gpu_device_count_hip(); }
 /* a stub in the reference (gpu/fft_gpu.c:359-363); real here: later allocations and plans go to `device` */
 int fft_gpu_set_device(int device) { return fft_gpu_set_device_hip(device); }
 
-/* 2D: stubs exactly like the reference (gpu/fft_gpu.c:377-394) -- out of scope for this path */
+/* 2D: real here (stubs returning NULL / -1 in the reference, gpu/fft_gpu.c:377-394) */
 fft_gpu_plan_t fft_gpu_plan_2d(int rows, int cols, fft_direction direction) {
-    (void)rows; (void)cols; (void)direction;
-    return NULL;
+    if (!backend_is_hip("fft_gpu_plan_2d")) return NULL;
+    return fft_gpu_plan_2d_hip(rows, cols, direction);
 }
 
+/* host arrays, row-major; one matrix */
 int fft_gpu_dft_2d(complex_t* in, complex_t* out, int rows, int cols, fft_direction direction) {
-    (void)in; (void)out; (void)rows; (void)cols; (void)direction;
-    return -1;
+    if (!in || !out || rows <= 0 || cols <= 0 || lazy_init() != 0) return -1;
+    const size_t n = (size_t)rows * (size_t)cols;
+    fft_gpu_plan_t plan = fft_gpu_plan_2d_hip(rows, cols, direction);
+    fft_gpu_memory_t buf = plan ? fft_gpu_alloc_hip(n) : NULL;
+    int rc = -1;
+    if (plan && buf) {
+        fft_gpu_copy_h2d_hip(buf, in, n);
+        if (fft_gpu_execute_ptr_hip(plan, fft_gpu_memory_ptr_hip(buf), fft_gpu_memory_ptr_hip(buf)) == 0 && fft_gpu_plan_sync_hip(plan) == 0) {
+            fft_gpu_copy_d2h_hip(out, buf, n);
+            rc = 0;
+        }
+    }
+    fft_gpu_free_hip(buf);
+    fft_gpu_destroy_plan_hip(plan);
+    return rc;
 }

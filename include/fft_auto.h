@@ -53,10 +53,16 @@ void fft_execute_dft(fft_plan_t plan, complex_t* in, complex_t* out);
 void fft_destroy_plan(fft_plan_t plan);
 int fft_auto(complex_t* in, complex_t* out, int n, int sign);
 
-/* stubs, as in the reference (fft_auto.c:391-426): out of scope for this path */
+/* reference fft_auto.h:88-124 (NULL / a use-after-free there, fft_auto.c:391-415; real here).  r2c: n reals ->
+ * n/2 + 1 bins; c2r: n/2 + 1 bins -> n reals scaled by 1/n; 2D: row-major rows x cols, inverse scaled once by
+ * 1/(rows*cols).  All executed with fft_execute(). */
 fft_plan_t fft_plan_r2c_1d(int n, double* in, complex_t* out, unsigned flags);
 fft_plan_t fft_plan_c2r_1d(int n, complex_t* in, double* out, unsigned flags);
 fft_plan_t fft_plan_dft_2d(int rows, int cols, complex_t* in, complex_t* out, int sign, unsigned flags);
+/* additive: which schedule FFT_MEASURE / FFT_PATIENT / FFT_EXHAUSTIVE kept for a plan (fft_gpu_algo_t of fft_hip.h; -1 =
+ * the plan was not measured), and a way to drop the plans fft_auto() keeps between calls */
+int fft_plan_measured_algo(fft_plan_t plan);
+void fft_auto_cleanup(void);
 char* fft_export_wisdom_to_string(void);
 int fft_import_wisdom_from_string(const char* wisdom);
 

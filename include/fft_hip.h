@@ -91,8 +91,20 @@ typedef struct {
 typedef enum {
     FFT_GPU_OPT_TEAM_FORCE_FALLBACK = 1, /* 1: the team kernel behaves as if it could not form its XCD teams (status 1, nothing
                                             touched) and the multi-pass plan queued behind it does the work */
-    FFT_GPU_OPT_TEAM_ENABLE = 2          /* 0: run the multi-pass schedule only; 1: back to the team kernel where the plan has one */
+    FFT_GPU_OPT_TEAM_ENABLE = 2,         /* 0: run the multi-pass schedule only; 1: back to the team kernel where the plan has one */
+    FFT_GPU_OPT_NO_FUSION = 3            /* 1: Bluestein / fused-consumer plans run their element-wise steps as kernels of their own
+                                            instead of fusing them into the FFT passes (same results to rounding; tests) */
 } fft_gpu_plan_option_t;
+
+/* Fused consumers of the transform (reference applications/convolution.c, applications/power_spectrum.c): FFT ->
+ * element-wise -> inverse FFT with the zero padding, the spectral product and the truncation fused into the FFT passes. */
+typedef enum {
+    FFT_GPU_FUSED_CONV_LINEAR = 0,   /* y = x * h, x: nx, h: nh (fixed at plan time), y: nx + nh - 1   convolution.c:34-69   */
+    FFT_GPU_FUSED_CONV_CIRCULAR = 1, /* y = x (*) h, all of length nx (a power of two)                   convolution.c:72-96   */
+    FFT_GPU_FUSED_AUTOCORR = 2,      /* first nx lags of IFFT(|FFT(x, zero padded)|^2)                   power_spectrum.c:133-158 */
+    FFT_GPU_FUSED_XCORR = 3,         /* first nx lags of IFFT(conj(FFT(x)) FFT(y))                       power_spectrum.c:161-190 */
+    FFT_GPU_FUSED_PSD = 4            /* one-sided Hann periodogram, nx/2 + 1 REAL values (nx a power of two) power_spectrum.c:58-86 */
+} fft_gpu_fused_t;
 
 /* backend-level additive entry points */
 int fft_gpu_device_count_hip(void);
@@ -103,7 +115,30 @@ int fft_gpu_copy_h2d_bytes_hip(fft_gpu_memory_t dst, const void* src, size_t byt
 int fft_gpu_copy_d2h_bytes_hip(void* dst, fft_gpu_memory_t src, size_t bytes);
 void* fft_gpu_memory_ptr_hip(fft_gpu_memory_t mem);
 size_t fft_gpu_memory_bytes_hip(fft_gpu_memory_t mem);
+/* page-lock / release a host array for the lifetime of a plan that borrows it (pinned H2D / D2H); 0 / -1 */
+int fft_gpu_host_register_hip(void* host_ptr, size_t bytes);
+int fft_gpu_host_unregister_hip(void* host_ptr);
+/* resource counters of this process (tests): device allocations and streams the backend has created so far */
+void fft_gpu_debug_counters_hip(long long* device_allocations, long long* streams_created);
+/* FFT_MEASURE at the device level: time the plan's candidate schedules (team kernel vs multi-pass) on scratch buffers of
+ * the plan's own size and keep the faster; returns 1 team kernel kept, 0 multi-pass kept / nothing to choose, -1 error */
+int fft_gpu_plan_measure_hip(fft_gpu_plan_t plan, int iters);
 fft_gpu_plan_t fft_gpu_plan_1d_ex_hip(int n, int batch, fft_direction dir, fft_precision_t prec, fft_gpu_algo_t algo);
+/* 2D complex transforms of `n_matrices` row-major rows x cols matrices: rows = one batched 1D execute, columns = the
+ * strided column pass of the four-step engine (or transpose + batched 1D); the inverse is scaled once by 1/(rows*cols).
+ * Execute with fft_gpu_execute(_ptr/_async); in == out allowed.  fft_gpu_plan_2d_hip replaces the stub gpu/fft_gpu.c:377-385. */
+fft_gpu_plan_t fft_gpu_plan_2d_hip(int rows, int cols, fft_direction dir);
+fft_gpu_plan_t fft_gpu_plan_2d_ex_hip(int rows, int cols, int n_matrices, fft_direction dir, fft_precision_t prec);
+/* real-input forward / real-output inverse 1D transforms (reference stubs algorithms/auto/fft_auto.c:391-409): r2c reads
+ * [batch][n] reals and writes [batch][n/2 + 1] complex bins; c2r the reverse, scaled by 1/n.  Execute with fft_gpu_execute_ptr. */
+fft_gpu_plan_t fft_gpu_plan_r2c_1d_hip(int n, int batch, fft_precision_t prec);
+fft_gpu_plan_t fft_gpu_plan_c2r_1d_hip(int n, int batch, fft_precision_t prec);
+/* fused consumers; h_host: the nh kernel samples (host memory, complex of `prec`) of the two convolutions, else ignored */
+fft_gpu_plan_t fft_gpu_plan_fused_hip(fft_gpu_fused_t kind, int nx, int nh, const void* h_host, int batch, fft_precision_t prec);
+int fft_gpu_fused_out_len_hip(fft_gpu_plan_t plan); /* elements per output row (complex; FFT_GPU_FUSED_PSD: real) */
+/* async on the plan's stream.  d_x: [batch][nx] complex; d_y: the second signal of FFT_GPU_FUSED_XCORR, else NULL;
+ * d_out: [batch][out_len]; sample_rate scales FFT_GPU_FUSED_PSD only */
+int fft_gpu_execute_fused_hip(fft_gpu_plan_t plan, const void* d_x, const void* d_y, void* d_out, double sample_rate);
 int fft_gpu_plan_info_hip(fft_gpu_plan_t plan, fft_gpu_plan_info_t* info);
 int fft_gpu_plan_set_stream_hip(fft_gpu_plan_t plan, void* hip_stream); /* NULL = the plan's own stream */
 int fft_gpu_execute_ptr_hip(fft_gpu_plan_t plan, const void* d_in, void* d_out); /* async on the plan's stream */

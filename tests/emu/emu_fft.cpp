@@ -4,6 +4,7 @@
 
 #include "emu_runtime.h"
 #include "fft_engine.h"
+#include "fft_plans_ext.h"
 
 namespace emu {
 thread_local dim3_ threadIdx_;
@@ -126,7 +127,11 @@ static int run(const void* in, void* out, int n, int batch, int dir, int algo, i
     } else {
         ffteng::BluesteinPlan<T, emu::Runtime> plan;
         if (!plan.build(&rt, n, dir, algo, batch)) return -1;
-        if (info) info[0] = 10 + (int)plan.core.passes.size();
+        if (getenv("FFT_EMU_NO_FUSION")) plan.no_fusion = true;
+        if (info) {
+            info[0] = 10 + (int)plan.core.passes.size();
+            info[4] = (plan.core.hook_capable() && !plan.no_fusion) ? 1 : 0;  // element-wise steps fused into the FFT passes
+        }
         plan.execute((const C*)in, (C*)out, batch);
     }
     return 0;
@@ -154,4 +159,54 @@ extern "C" int emu_bitrev(const void* in, void* out, int n, int batch, int prec)
     else
         rt.launch(fftk::bitrev_kernel<double>, 4, 256, (size_t)0, (const fftk::cpx<double>*)in, (fftk::cpx<double>*)out, log2n, total);
     return 0;
+}
+
+// ---- plans built on the engine (fft_plans_ext.h)
+template <typename T>
+static int run2d(const void* in, void* out, int rows, int cols, int nm, int dir, int lds_budget, int* info) {
+    emu::Runtime rt;
+    if (lds_budget > 0) rt.lds_budget = lds_budget;
+    ffteng::Plan2D<T, emu::Runtime> plan;
+    if (!plan.build(&rt, rows, cols, dir, nm)) return -1;
+    if (info) info[0] = plan.colp ? 1 : (plan.colt ? 2 : 0);  // 1 direct column pass, 2 transpose path
+    plan.execute((const fftk::cpx<T>*)in, (fftk::cpx<T>*)out, nm);
+    return 0;
+}
+extern "C" int emu_fft2d(const void* in, void* out, int rows, int cols, int nm, int dir, int prec, int lds_budget, int* info) {
+    return prec == 1 ? run2d<float>(in, out, rows, cols, nm, dir, lds_budget, info) : run2d<double>(in, out, rows, cols, nm, dir, lds_budget, info);
+}
+
+template <typename T>
+static int run_real(const void* in, void* out, int n, int batch, int r2c) {
+    emu::Runtime rt;
+    ffteng::RealPlan<T, emu::Runtime> plan;
+    if (!plan.build(&rt, n, r2c != 0, batch)) return -1;
+    if (r2c) plan.execute_r2c((const T*)in, (fftk::cpx<T>*)out, batch);
+    else plan.execute_c2r((const fftk::cpx<T>*)in, (T*)out, batch);
+    return 0;
+}
+extern "C" int emu_real(const void* in, void* out, int n, int batch, int r2c, int prec) {
+    return prec == 1 ? run_real<float>(in, out, n, batch, r2c) : run_real<double>(in, out, n, batch, r2c);
+}
+
+template <typename T>
+static int run_fused(int kind, const void* x, const void* y, const void* h, int nx, int nh, void* out, int batch, int lds_budget, int no_fusion,
+                     double fs, int* info) {
+    emu::Runtime rt;
+    if (lds_budget > 0) rt.lds_budget = lds_budget;
+    ffteng::FusedPlan<T, emu::Runtime> plan;
+    if (!plan.build(&rt, kind, nx, nh, (const fftk::cpx<T>*)h, batch)) return -1;
+    plan.no_fusion = no_fusion != 0;
+    if (info) {
+        info[0] = (int)plan.core.passes.size();
+        info[1] = plan.fused() ? 1 : 0;
+        info[2] = plan.log2m;
+    }
+    plan.execute((const fftk::cpx<T>*)x, (const fftk::cpx<T>*)y, out, batch, (T)fs);
+    return 0;
+}
+extern "C" int emu_fused(int kind, const void* x, const void* y, const void* h, int nx, int nh, void* out, int batch, int prec, int lds_budget,
+                         int no_fusion, double fs, int* info) {
+    return prec == 1 ? run_fused<float>(kind, x, y, h, nx, nh, out, batch, lds_budget, no_fusion, fs, info)
+                     : run_fused<double>(kind, x, y, h, nx, nh, out, batch, lds_budget, no_fusion, fs, info);
 }

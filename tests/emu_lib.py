@@ -77,3 +77,74 @@ def emu_fft_team(x, direction=-1, log2seats=2, n_xcc=2, threads=16, lds_budget=0
     if rc != 0:
         raise RuntimeError("emu_fft_team failed")
     return out, list(info)
+
+
+def emu_fft2d(x, direction=-1, lds_budget=0, inplace=False):
+    """x: [matrices, rows, cols] (or [rows, cols]) complex.  Returns (result, info); info[0] = 1 direct column pass, 2 transpose path."""
+    x = np.ascontiguousarray(x)
+    x3 = x.reshape((-1,) + x.shape[-2:])
+    nm, rows, cols = x3.shape
+    prec = 1 if x.dtype == np.complex64 else 0
+    info = (C.c_int * 8)()
+    out = x3.copy() if inplace else np.full_like(x3, np.nan)
+    src = out if inplace else x3
+    lib().emu_fft2d.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.POINTER(C.c_int)]
+    if lib().emu_fft2d(src.ctypes.data, out.ctypes.data, rows, cols, nm, direction, prec, lds_budget, info) != 0:
+        raise RuntimeError("emu_fft2d failed")
+    return out.reshape(x.shape), list(info)
+
+
+def emu_r2c(x):
+    """x: [batch, n] float32/float64 -> [batch, n//2 + 1] complex."""
+    x = np.ascontiguousarray(x)
+    batch, n = x.shape
+    prec = 1 if x.dtype == np.float32 else 0
+    out = np.full((batch, n // 2 + 1), np.nan, dtype=np.complex64 if prec else np.complex128)
+    lib().emu_real.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 4
+    if lib().emu_real(x.ctypes.data, out.ctypes.data, n, batch, 1, prec) != 0:
+        raise RuntimeError("emu_real failed")
+    return out
+
+
+def emu_c2r(X, n):
+    """X: [batch, n//2 + 1] complex -> [batch, n] real (scaled by 1/n)."""
+    X = np.ascontiguousarray(X)
+    batch = X.shape[0]
+    prec = 1 if X.dtype == np.complex64 else 0
+    out = np.full((batch, n), np.nan, dtype=np.float32 if prec else np.float64)
+    lib().emu_real.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 4
+    if lib().emu_real(X.ctypes.data, out.ctypes.data, n, batch, 0, prec) != 0:
+        raise RuntimeError("emu_real failed")
+    return out
+
+
+FUSED = {"conv": 0, "circ": 1, "autocorr": 2, "xcorr": 3, "psd": 4}
+
+
+def emu_fused(kind, x, y=None, h=None, lds_budget=0, no_fusion=False, fs=1.0):
+    """x: [batch, nx] complex; h: [nh] kernel (conv / circ); y: [batch, nx] (xcorr).  Returns (result, info);
+    info = [passes, fused?, log2 m]."""
+    x = np.ascontiguousarray(x)
+    batch, nx = x.shape
+    prec = 1 if x.dtype == np.complex64 else 0
+    k = FUSED[kind]
+    nh = 0 if h is None else len(h)
+    if h is not None:
+        h = np.ascontiguousarray(h.astype(x.dtype))
+    if y is not None:
+        y = np.ascontiguousarray(y.astype(x.dtype))
+    if kind == "conv":
+        out = np.full((batch, nx + nh - 1), np.nan, dtype=x.dtype)
+    elif kind == "psd":
+        out = np.full((batch, nx // 2 + 1), np.nan, dtype=np.float32 if prec else np.float64)
+    else:
+        out = np.full((batch, nx), np.nan, dtype=x.dtype)
+    info = (C.c_int * 8)()
+    f = lib().emu_fused
+    f.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
+                  C.POINTER(C.c_int)]
+    rc = f(k, x.ctypes.data, None if y is None else y.ctypes.data, None if h is None else h.ctypes.data, nx, nh, out.ctypes.data, batch, prec,
+           lds_budget, 1 if no_fusion else 0, fs, info)
+    if rc != 0:
+        raise RuntimeError("emu_fused failed")
+    return out, list(info)

@@ -11,10 +11,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def declared_symbols():
     names = set()
-    for h in ("fft_gpu.h", "fft_hip.h", "fft_auto.h", "fft_algorithms.h"):
+    for h in ("fft_gpu.h", "fft_hip.h", "fft_auto.h", "fft_algorithms.h", "fft_apps.h", "fft_utils.h"):
         text = open(os.path.join(ROOT, "include", h)).read()
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-        for m in re.finditer(r"\b((?:fft|radix|split|bluestein)[a-z0-9_]*)\s*\(", text):
+        for m in re.finditer(r"\b((?:fft|radix|split|bluestein|circular|compute_periodogram|autocorrelation|cross_correlation|save_complex|load_complex)[a-z0-9_]*)\s*\(", text):
             names.add(m.group(1))
     return names
 

@@ -1,0 +1,99 @@
+"""CPU emulation (tests/emu) of the plans built on the batched engine for the "next" rows of the scope table
+(SURVEY.md 8f): 2D complex transforms, r2c / c2r, fused convolution / correlation / periodogram -- the unmodified
+planner and kernel source against the oracle's restatement of the reference's applications."""
+import numpy as np
+import pytest
+
+import emu_lib as E
+import oracle_lib as O
+
+
+def rel(a, b):
+    return float(np.linalg.norm(np.asarray(a, dtype=np.complex128) - b) / np.linalg.norm(b))
+
+
+TOL = {np.dtype(np.complex64): 3e-5, np.dtype(np.complex128): 1e-12, np.dtype(np.float32): 3e-5, np.dtype(np.float64): 1e-12}
+
+
+def lcg(shape, seed, dtype):
+    n = int(np.prod(shape))
+    return O.gen_lcg(n, seed, 1).reshape(shape).astype(dtype)
+
+
+@pytest.mark.parametrize("rows,cols,nm,dtype,lds,path", [
+    (32, 64, 2, np.complex64, 0, 1),      # direct column pass
+    (64, 32, 1, np.complex128, 0, 1),
+    (16, 24, 3, np.complex64, 0, 1),      # cols not a power of two (rows: Bluestein over cols), still a multiple of the lane access
+    (8, 5, 2, np.complex64, 0, 2),        # odd cols: 16-byte accesses impossible -> transpose path
+    (12, 32, 2, np.complex128, 0, 2),     # rows not a power of two -> transpose + Bluestein
+    (256, 8, 1, np.complex64, 1024, 2),   # rows do not fit one LDS tile of this budget -> transpose path
+    (1, 64, 2, np.complex64, 0, 0),       # a single row: rows only
+])
+def test_fft2d_emulated(rows, cols, nm, dtype, lds, path):
+    x = lcg((nm, rows, cols), rows * 131 + cols, dtype)
+    for d in (-1, 1):
+        for inplace in (False, True):
+            y, info = E.emu_fft2d(x, d, lds_budget=lds, inplace=inplace)
+            assert info[0] == path, info[0]
+            assert rel(y, O.oracle_fft2d(x.astype(np.complex128), d)) < TOL[np.dtype(dtype)], (d, inplace)
+    # round trip: the inverse is scaled once
+    y, _ = E.emu_fft2d(x, -1, lds_budget=lds)
+    z, _ = E.emu_fft2d(y, 1, lds_budget=lds)
+    assert rel(z, x.astype(np.complex128)) < TOL[np.dtype(dtype)]
+
+
+@pytest.mark.parametrize("n", [2, 4, 8, 64, 1024, 6, 100, 1, 3, 9, 31, 101])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_r2c_c2r_emulated(n, dtype):
+    batch = 3
+    x = lcg((batch, n), n + 5, np.complex128).real.astype(dtype)
+    X = E.emu_r2c(x)
+    ref = O.oracle_r2c(x.astype(np.float64))
+    assert X.shape == (batch, n // 2 + 1)
+    assert rel(X, ref) < TOL[np.dtype(dtype)], n
+    back = E.emu_c2r(X, n)
+    assert np.linalg.norm(back - x) / np.linalg.norm(x) < TOL[np.dtype(dtype)] * 2, n
+    assert rel(E.emu_c2r(ref.astype(X.dtype), n), O.oracle_c2r(ref, n)) < TOL[np.dtype(dtype)] * 2
+
+
+@pytest.mark.parametrize("nx,nh,dtype,lds", [(100, 17, np.complex128, 0), (100, 17, np.complex64, 0), (101, 8, np.complex64, 0),
+                                             (700, 401, np.complex128, 8192), (1, 1, np.complex128, 0), (5, 1, np.complex64, 0)])
+def test_fused_linear_convolution_emulated(nx, nh, dtype, lds):
+    x = lcg((4, nx), nx, dtype)
+    h = lcg((nh,), nh + 3, dtype)
+    ref = O.oracle_conv_linear(x.astype(np.complex128), h.astype(np.complex128))
+    for no_fusion in (False, True):
+        y, info = E.emu_fused("conv", x, h=h, lds_budget=lds, no_fusion=no_fusion)
+        assert info[1] == (0 if (no_fusion or info[2] == 0) else 1), info
+        assert rel(y, ref) < TOL[np.dtype(dtype)] * 4, (nx, nh, no_fusion)
+    # and against the defining sum (reference direct_convolution, convolution.c:19-31)
+    direct = np.stack([np.convolve(r, h.astype(np.complex128)) for r in x.astype(np.complex128)])
+    assert rel(ref, direct) < 1e-11
+
+
+@pytest.mark.parametrize("kind,n,dtype,lds", [("circ", 64, np.complex128, 0), ("circ", 2048, np.complex64, 4096),
+                                              ("autocorr", 100, np.complex128, 0), ("autocorr", 1000, np.complex64, 4096),
+                                              ("xcorr", 100, np.complex128, 0), ("xcorr", 333, np.complex64, 0),
+                                              ("xcorr", 1500, np.complex128, 4096)])
+def test_fused_correlations_emulated(kind, n, dtype, lds):
+    x = lcg((3, n), n, dtype)
+    y = lcg((3, n), n + 1, dtype)
+    h = lcg((n,), n + 2, dtype)
+    x64, y64, h64 = (a.astype(np.complex128) for a in (x, y, h))
+    ref = {"circ": lambda: O.oracle_conv_circular(x64, h64), "autocorr": lambda: O.oracle_autocorr(x64),
+           "xcorr": lambda: O.oracle_xcorr(x64, y64)}[kind]()
+    for no_fusion in (False, True):
+        out, info = E.emu_fused(kind, x, y=y if kind == "xcorr" else None, h=h if kind == "circ" else None, lds_budget=lds,
+                                no_fusion=no_fusion)
+        assert info[1] == (0 if no_fusion else 1)
+        assert rel(out, ref) < TOL[np.dtype(dtype)] * 4, (kind, n, no_fusion)
+
+
+@pytest.mark.parametrize("n,dtype,lds", [(64, np.complex128, 0), (1024, np.complex64, 0), (4096, np.complex128, 4096)])
+def test_fused_periodogram_emulated(n, dtype, lds):
+    x = lcg((3, n), n, dtype)
+    ref = O.oracle_periodogram(x.astype(np.complex128), 48000.0)
+    for no_fusion in (False, True):
+        psd, info = E.emu_fused("psd", x, lds_budget=lds, no_fusion=no_fusion, fs=48000.0)
+        assert psd.shape == (3, n // 2 + 1)
+        assert np.linalg.norm(psd - ref) / np.linalg.norm(ref) < TOL[np.dtype(dtype)] * 4

@@ -94,6 +94,34 @@ def test_bluestein_emulated():
             assert rel(y, O.oracle_fft(x, d, "bluestein")) < 1e-12
 
 
+@pytest.mark.parametrize("n,dtype,lds,passes", [
+    (100, np.complex64, 0, 1),        # single-pass hooks, fp32 pairs, even pitch
+    (101, np.complex64, 0, 1),        # odd pitch: the user's rows are not 16-byte aligned -> value-by-value accesses
+    (1009, np.complex64, 0, 1),       # m = 2048, odd n: the last pair straddles n
+    (1009, np.complex128, 4096, 2),   # m = 2048 in two passes: load hook on the column pass, store hooks on the row pass
+    (1009, np.complex64, 4096, 2),
+    (1500, np.complex64, 4096, 3),     # m = 4096
+    (3001, np.complex128, 2048, 3),   # m = 8192 in three passes
+    (3001, np.complex64, 2048, 3),
+])
+def test_bluestein_fused_ends(n, dtype, lds, passes, monkeypatch):
+    """Bluestein with its modulate / pointwise / demodulate steps fused into the first load and last store of the two
+    power-of-two transforms (fftk::TileHooks) against the oracle, and bit-for-bit ... no: to rounding ... against the
+    same plan run with the three steps as kernels of their own."""
+    batch = 5
+    x = O.gen_lcg(n, n, batch).astype(dtype)
+    tol = 1e-12 if dtype == np.complex128 else 2e-5
+    for d in (-1, 1):
+        for inplace in (False, True):
+            y, info = E.emu_fft(x, d, lds_budget=lds, inplace=inplace)
+            assert info[0] == 10 + passes and info[4] == 1, info[:5]
+            assert rel(y, O.oracle_fft(x.astype(np.complex128), d, "bluestein")) < tol, (n, d, inplace)
+    monkeypatch.setenv("FFT_EMU_NO_FUSION", "1")
+    y2, info = E.emu_fft(x, -1, lds_budget=lds)
+    assert info[4] == 0
+    assert rel(y2, O.oracle_fft(x.astype(np.complex128), -1, "bluestein")) < tol
+
+
 def test_bit_reversal_kernel_emulated(golden):
     import ctypes as C
     n = 1024
