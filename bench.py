@@ -215,7 +215,65 @@ def cpu_fp32_comparators(n, threads):
                                                   "note": "oracle_radix2_dit_f32, OpenMP over %d transforms" % batch}
     except Exception as e:
         res["port_fp32_radix2_dit_all_cores"] = {"value": None, "note": "failed: %r" % (e,)}
+    try:
+        # the SoA 4-wide variant SURVEY.md 8d asks for: optimizations/simd_fft.c's structure (split real[] / imag[], four
+        # butterflies per step, :143-230) with a correct twiddle per lane -- oracle_radix2_soa4_f32
+        lib = C.CDLL(os.path.join(ROOT, "oracle", "liboracle_fast.so"))
+        lib.oracle_radix2_soa4_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        lib.oracle_soa4_batch_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_long, C.c_int]
+        import oracle_lib as O
+        batch = max(threads, 8)
+        x0 = O.gen_two_tone(n, 0, batch, np.complex64)
+        re0, im0 = np.ascontiguousarray(x0.real), np.ascontiguousarray(x0.imag)
+        best1 = 1e9
+        for _ in range(3):
+            re, im = re0[0].copy(), im0[0].copy()
+            t0 = time.perf_counter()
+            lib.oracle_radix2_soa4_f32(re.ctypes.data, im.ctypes.data, n, -1)
+            best1 = min(best1, time.perf_counter() - t0)
+        re, im = re0.copy(), im0.copy()
+        lib.oracle_soa4_batch_f32(re.ctypes.data, im.ctypes.data, n, batch, -1)
+        re[:], im[:] = re0, im0
+        t0 = time.perf_counter()
+        lib.oracle_soa4_batch_f32(re.ctypes.data, im.ctypes.data, n, batch, -1)
+        dt = time.perf_counter() - t0
+        res["port_fp32_soa4_radix2_1thread"] = {"value": n / best1 / 1e9, "unit": "Gpoint/s", "cores": 1,
+                                                "note": "oracle_radix2_soa4_f32: simd_fft.c's SoA 4-wide structure, correct per-lane twiddles"}
+        res["port_fp32_soa4_radix2_all_cores"] = {"value": float(n) * batch / dt / 1e9, "unit": "Gpoint/s", "cores": threads,
+                                                  "note": "the same, OpenMP over %d transforms" % batch}
+    except Exception as e:
+        res["port_fp32_soa4_radix2_1thread"] = {"value": None, "note": "failed: %r" % (e,)}
     return res
+
+
+def kernel_source_hash():
+    """Identity of the kernels a PMC profile was taken on: sha256 over the kernel sources.  profiles/pmc_traffic.json
+    entries carry it; a traffic figure is attached to the bench line only when it still matches (the
+    committed figure must not silently outlive the kernel it was measured on)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "fft-implementation-in-c_amd", "csrc")
+    for f in ("fft_device.h", "fft_codelets.h", "fft_kernels.h", "fft_team.h", "fft_team_defer.h", "fft_team_list.h"):
+        with open(os.path.join(d, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def device_copy_gbs(torch, x, y, iters=10):
+    """What a plain device copy of the same buffers achieves on THIS box (read + written bytes per second): the
+    practical ceiling the guide quotes at 6.29 TB/s; roofline.frac_of_copy = achieved / this."""
+    y.copy_(x)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    best = 1e9
+    for _ in range(3):
+        e0.record()
+        for _ in range(iters):
+            y.copy_(x)
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) / iters)
+    return 2.0 * x.numel() * x.element_size() / (best * 1e-3) / 1e9
 
 
 def main():
@@ -228,7 +286,13 @@ def main():
     ap.add_argument("--inplace", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the fp64 2^19 secondary line and the device copy")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help="(internal) print the CPU baseline JSON for --workload and exit")
     args = ap.parse_args()
+    if args.cpu_baseline_only:  # child process of the main run: a crash here (e.g. SIGILL in a comparator) cannot lose the GPU line
+        n, batch, dtype, desc = WORKLOADS[args.workload]
+        print(json.dumps(cpu_baseline(n, dtype)), flush=True)
+        return
 
     import numpy as np
     import torch
@@ -318,6 +382,9 @@ def main():
     # ---- device-side duration of the same K steps, HIP events on the stream the kernels run on
     ev_ms = plan.timed(x.data_ptr(), y.data_ptr(), args.steps)
     torch.cuda.synchronize()
+    # per-step device times (one HIP-event pair per step): median and min next to the mean of the timed region
+    step_ms = sorted(plan.timed(x.data_ptr(), y.data_ptr(), 1) for _ in range(max(5, min(args.steps, 50))))
+    torch.cuda.synchronize()
     # which schedule ran?  0: the one-round-trip team kernel (fft_team.h) did the work; 1: its XCD teams could not be
     # formed and the multi-pass fallback queued behind it did; -1: the plan has no team kernel (multi-pass schedule)
     team_status = plan.team_status()
@@ -364,18 +431,23 @@ def main():
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             pt = json.load(f)
-        ent = pt.get(args.workload)
         ent = pt.get(args.workload + ("_team" if team else ""))
         if ent and ent.get("factors") == [v for v in info.factors if v] and ent.get("units_per_launch") == units_per_launch:
-            traffic = ent["hbm_bytes_per_launch_set"]
-            traffic_note = ent["note"]
+            if ent.get("kernel_source_hash") == kernel_source_hash():
+                traffic = ent["hbm_bytes_per_launch_set"]
+                traffic_note = ent["note"]
+            else:
+                traffic_note = ("profiles/pmc_traffic.json holds a figure for this workload, taken on other kernel sources (hash %s, now %s): "
+                                "not attached; re-run tools/profile_round.sh" % (ent.get("kernel_source_hash"), kernel_source_hash()))
     except Exception:
         pass
 
     result = {
         "metric": "Gpoint/s + achieved HBM GB/s, batched 1D c2c FFT at 1/2/4/8 MI355X",
         "value": value, "unit": "Gpoint/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": ms_per_step, "ms_per_step_median": step_ms[len(step_ms) // 2], "ms_per_step_min": step_ms[0],
+        "value_median": float(n) * batch * world / (step_ms[len(step_ms) // 2] * 1e-3) / 1e9,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": dtype, "data": "synthetic",
         "achieved_hbm_gbs": 2.0 * n * batch * world * esz / (elapsed / args.steps) / 1e9,
         "config": {
@@ -406,9 +478,47 @@ def main():
         },
         "check": check,
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if not args.no_secondary:
+        # the practical ceiling on this box, and an fp64 line (N = 2^19 is the largest fp64 team-kernel size)
         try:
-            result["cpu_baseline"] = cpu_baseline(n, dtype)
+            copy = device_copy_gbs(torch, x, y if not args.inplace else torch.empty_like(x))
+            result["roofline"]["copy_gbs"] = copy
+            result["roofline"]["frac_of_copy"] = achieved / copy
+        except Exception as e:
+            result["roofline"]["copy_gbs"] = None
+            result["roofline"]["copy_note"] = "failed: %r" % (e,)
+        if world == 1 and args.workload == "1m":
+            try:
+                del x, y
+                torch.cuda.empty_cache()
+                n2, b2 = 1 << 19, 256
+                p2 = fftlib.Plan(n2, b2, fftlib.FFT_FORWARD, np.complex128)
+                p2.set_stream(stream.cuda_stream)
+                x2 = make_input(torch, n2, b2, "f64", 0, device)
+                y2 = torch.empty_like(x2)
+                p2.timed(x2.data_ptr(), y2.data_ptr(), 2)
+                t2 = sorted(p2.timed(x2.data_ptr(), y2.data_ptr(), 1) for _ in range(10))
+                st2 = p2.team_status()
+                bb = torch.arange(b2, dtype=torch.int64, device=device)
+                pk = y2[torch.arange(b2, device=device), (1 + 7 * bb) % n2]
+                ok2 = float((pk - n2).abs().max()) / n2 < 1e-6
+                med = t2[len(t2) // 2]
+                result["secondary_fp64"] = {
+                    "workload": "N=524288 fp64 complex, batch=256", "value": float(n2) * b2 / (med * 1e-3) / 1e9, "unit": "Gpoint/s",
+                    "ms_per_step_median": med, "ms_per_step_min": t2[0], "achieved_gbs": 2.0 * n2 * b2 * 16 / (med * 1e-3) / 1e9,
+                    "frac": 2.0 * n2 * b2 * 16 / (med * 1e-3) / 1e9 / HBM_PEAK_GBS, "team_status": st2, "check_ok": ok2}
+                p2.destroy()
+                del x2, y2
+            except Exception as e:
+                result["secondary_fp64"] = {"value": None, "note": "failed: %r" % (e,)}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # in a child process: the comparators load CPU libraries built on another host; whatever happens to them, the
+        # GPU line below is printed
+        try:
+            import subprocess
+            out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--workload", args.workload],
+                                 capture_output=True, text=True, timeout=600)
+            result["cpu_baseline"] = json.loads(out.stdout.strip().splitlines()[-1])
         except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
             result["cpu_baseline"] = {"value": None, "unit": "Gpoint/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
     elif rank == 0:

@@ -735,6 +735,16 @@ int fft_gpu_host_unregister_hip(void* host_ptr) {
     }
     return 0;
 }
+// 1: the address is page-locked host memory known to the runtime (hipHostRegister / hipHostMalloc), 0: it is not
+int fft_gpu_host_is_registered_hip(const void* host_ptr) {
+    if (!host_ptr) return 0;
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, host_ptr) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return attr.type == hipMemoryTypeHost ? 1 : 0;
+}
 void fft_gpu_debug_counters_hip(long long* device_allocations, long long* streams_created) {
     if (device_allocations) *device_allocations = __atomic_load_n(&g_count_allocs, __ATOMIC_RELAXED);
     if (streams_created) *streams_created = __atomic_load_n(&g_count_streams, __ATOMIC_RELAXED);

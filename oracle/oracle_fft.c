@@ -381,6 +381,79 @@ int oracle_radix2_dit_f32(float* x, int n, int dir) {
     return 0;
 }
 
+/* fp32 SoA (split real[] / imag[]) radix-2 DIT, FOUR butterflies per step -- the structure of the reference's
+ * optimizations/simd_fft.c:92-95 (complex_float_split_t), :114-140 (butterfly_sse2: 4 butterflies per _mm_load_ps) and
+ * :143-230 (fft_radix2_sse2: bit reversal on the split arrays, then log2 n stages), but with a CORRECT twiddle for each of
+ * the four lanes (the reference applies one twiddle to four adjacent butterflies and advances it by one step,
+ * simd_fft.c:179-189; its self-test prints a 9.27 maximum error).  Twiddles per stage are gathered
+ * into contiguous split arrays so the 4-wide loop below is straight loads / multiplies / stores that gcc turns into
+ * SSE / AVX code at the reference's flags.  re / im: n floats each, 16-byte aligned.  Timing comparator and checker. */
+int oracle_radix2_soa4_f32(float* re, float* im, int n, int dir) {
+    if (!oracle_is_power_of_two(n)) return -1;
+    const int log2n = oracle_log2_int(n);
+    float* wr = (float*)malloc(sizeof(float) * (size_t)(n > 1 ? n : 2));
+    if (!wr) return -1;
+    float* wi = wr + n / 2 + (n < 2);
+    for (int i = 0; i < n; i++) {
+        const int j = (int)oracle_bit_reverse((unsigned)i, log2n);
+        if (i < j) {
+            float t = re[i]; re[i] = re[j]; re[j] = t;
+            t = im[i]; im[i] = im[j]; im[j] = t;
+        }
+    }
+    for (int stage = 1; stage <= log2n; stage++) {
+        const int m = 1 << stage, half = m >> 1;
+        for (int j = 0; j < half; j++) {  /* this stage's twiddles W_m^j, contiguous */
+            const double ang = dir * ORACLE_TWO_PI * (double)j / (double)m;
+            wr[j] = (float)cos(ang);
+            wi[j] = (float)sin(ang);
+        }
+        for (int k = 0; k < n; k += m) {
+            float* tr = re + k;
+            float* ti = im + k;
+            float* ur = re + k + half;
+            float* ui = im + k + half;
+            int j = 0;
+            for (; j + 4 <= half; j += 4) {  /* four butterflies, four twiddles */
+                float pr[4], pi[4];
+                for (int l = 0; l < 4; l++) {
+                    pr[l] = ur[j + l] * wr[j + l] - ui[j + l] * wi[j + l];
+                    pi[l] = ur[j + l] * wi[j + l] + ui[j + l] * wr[j + l];
+                }
+                for (int l = 0; l < 4; l++) {
+                    ur[j + l] = tr[j + l] - pr[l];
+                    ui[j + l] = ti[j + l] - pi[l];
+                    tr[j + l] += pr[l];
+                    ti[j + l] += pi[l];
+                }
+            }
+            for (; j < half; j++) {  /* the first two stages: fewer than four butterflies per block */
+                const float pr = ur[j] * wr[j] - ui[j] * wi[j], pi = ur[j] * wi[j] + ui[j] * wr[j];
+                ur[j] = tr[j] - pr;
+                ui[j] = ti[j] - pi;
+                tr[j] += pr;
+                ti[j] += pi;
+            }
+        }
+    }
+    if (dir > 0) {
+        const float s = 1.0f / (float)n;
+        for (int i = 0; i < n; i++) { re[i] *= s; im[i] *= s; }
+    }
+    free(wr);
+    return 0;
+}
+
+/* batch of split-array transforms: transform b at re + b*n, im + b*n; OpenMP over the batch index */
+int oracle_soa4_batch_f32(float* re, float* im, int n, long batch, int dir) {
+    int rc = 0;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) reduction(| : rc)
+#endif
+    for (long b = 0; b < batch; b++) rc |= (oracle_radix2_soa4_f32(re + (size_t)b * (size_t)n, im + (size_t)b * (size_t)n, n, dir) != 0);
+    return rc ? -1 : 0;
+}
+
 /* Batched drivers: transform b occupies [b*n, (b+1)*n) -- the contiguous
  * layout of cufftPlanMany in gpu/fft_cuda.cu:152-156.  algo: 0 dit,
  * 1 dif, 2 split_radix, 3 radix4, 4 bluestein, 5 exact-twiddle dit, 6 naive.

@@ -226,7 +226,10 @@ def test_bluestein_fused_equals_unfused_and_oracle(gpu_lib, n, batch, dtype):
             res.append(buf.download(x.shape, dtype))
         ref = O.oracle_fft(x[:1].astype(np.complex128), d, "bluestein")
         r = rel(res[0][:1], ref)
-        assert r <= TOL[np.dtype(dtype)] and r <= TIGHT[np.dtype(dtype)] * 16, (n, d, r)
+        # the reference's own error grows ~ n eps (twiddle recurrence, SURVEY.md fact 8: 2e-10 at n = 10^6): the oracle
+        # restates it, so the fp64 bound against it is loosened with n; fused vs unfused below stays tight
+        tight = max(TIGHT[np.dtype(dtype)] * 16, 1e-15 * n)
+        assert r <= TOL[np.dtype(dtype)] and r <= tight, (n, d, r)
         assert rel(res[0], res[1].astype(np.complex128)) <= TIGHT[np.dtype(dtype)] * 16
         plan.destroy()
     buf.free()
@@ -306,12 +309,16 @@ def test_planner_pins_the_borrowed_arrays(gpu_lib):
     lib = gpu_lib
     n = 1 << 16
     x = lcg((n,), 2, np.complex128)
-    plan = lib.fft_plan_dft_1d(n, x.ctypes.data, x.ctypes.data, -1, 0)
+    y = np.empty_like(x)
+    assert lib.fft_gpu_host_is_registered_hip(x.ctypes.data) == 0
+    plan = lib.fft_plan_dft_1d(n, x.ctypes.data, y.ctypes.data, -1, 0)
     assert plan
-    assert lib.fft_gpu_host_register_hip(x.ctypes.data, x.nbytes) == -1, "already page-locked by the plan"
-    ref = O.oracle_fft(x, -1, "dit")
+    assert lib.fft_gpu_host_is_registered_hip(x.ctypes.data) == 1 and lib.fft_gpu_host_is_registered_hip(y.ctypes.data) == 1
     lib.fft_execute(plan)
     lib.fft_destroy_plan(plan)
-    assert rel(x, ref) < 1e-11
-    assert lib.fft_gpu_host_register_hip(x.ctypes.data, x.nbytes) == 0  # released by the destroy
-    assert lib.fft_gpu_host_unregister_hip(x.ctypes.data) == 0
+    assert rel(y, O.oracle_fft(x, -1, "dit")) < 1e-11
+    assert lib.fft_gpu_host_is_registered_hip(x.ctypes.data) == 0 and lib.fft_gpu_host_is_registered_hip(y.ctypes.data) == 0
+    FFT_CONSERVE_MEMORY = 1 << 8
+    plan = lib.fft_plan_dft_1d(n, x.ctypes.data, y.ctypes.data, -1, FFT_CONSERVE_MEMORY)
+    assert plan and lib.fft_gpu_host_is_registered_hip(x.ctypes.data) == 0
+    lib.fft_destroy_plan(plan)

@@ -222,7 +222,10 @@ def test_c_api_fft_auto_and_plan(gpu_lib):
     tot, av = C.c_size_t(), C.c_size_t()
     gpu_lib.fft_gpu_get_memory_info(C.byref(tot), C.byref(av))
     assert tot.value > (100 << 30) and 0 < av.value <= tot.value
-    assert gpu_lib.fft_gpu_plan_2d(4, 4, -1) is None and gpu_lib.fft_gpu_dft_2d(None, None, 4, 4, -1) == -1
+    p2 = gpu_lib.fft_gpu_plan_2d(4, 4, -1)  # a stub (NULL) in the reference and in round 1; real since round 2 (tests/test_gpu_ext.py)
+    assert p2 is not None
+    gpu_lib.fft_gpu_destroy_plan(p2)
+    assert gpu_lib.fft_gpu_dft_2d(None, None, 4, 4, -1) == -1
 
 
 def test_reference_property_tests(gpu_lib):

@@ -1,7 +1,8 @@
 """N > 1: the batch is sharded by batch index, one process per GPU, no data-path collective.  These CPU tests
 run bench.py's sharding / timing-reduction logic with world_size 2 over gloo (no GPU needed): every rank owns
-`batch` whole transforms, the union covers [0, world*batch) exactly once, and the only communication is the
-barrier + MAX all-reduce of the elapsed time."""
+`batch` whole transforms and transforms them with the ENGINE (planner + kernels in the CPU emulation, tests/emu;
+both the multi-pass schedule and the team kernel), the union covers [0, world*batch) exactly once, and the only
+communication is the barrier + MAX all-reduce of the elapsed time."""
 import os
 import socket
 import subprocess
@@ -25,18 +26,24 @@ WORKER = textwrap.dedent('''
     import torch, torch.distributed as dist
     sys.path.insert(0, os.path.join(%r, "tests"))
     import oracle_lib as O
+    import emu_lib as E
     from bench import shard_range, reduce_max_seconds
     dist.init_process_group(backend="gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
-    n, per_gpu = 256, 6
+    n, per_gpu = 4096, 6
     b0, b1 = shard_range(rank, world, per_gpu)
-    # each rank transforms its own shard with the oracle (the GPU engine's stand-in on this CPU-only box)
-    x = O.gen_two_tone(n, b0, b1 - b0)
-    X = O.oracle_fft(x, -1, "dit")
-    ok = True
+    # each rank transforms ITS OWN shard with the ENGINE -- the unmodified planner + kernel source running in the CPU
+    # emulation (tests/emu), two-pass plan and the team kernel -- never with the oracle; the oracle only checks
+    x = O.gen_two_tone(n, b0, b1 - b0).astype(np.complex64)
+    X, info = E.emu_fft(x, -1, lds_budget=16384)                       # multi-pass schedule (64 x 64)
+    Xt, info_t = E.emu_fft_team(x, -1, log2seats=2, n_xcc=2, threads=16, lds_budget=16384)   # team kernel, 2 "XCDs" of 4 seats
+    ok = info[0] == 2 and info_t[0] >= 400
+    ref = O.oracle_fft(x.astype(np.complex128), -1, "dit")
+    ok &= float(np.linalg.norm(X - ref) / np.linalg.norm(ref)) < 2e-6
+    ok &= float(np.linalg.norm(Xt - ref) / np.linalg.norm(ref)) < 2e-6
     for i, b in enumerate(range(b0, b1)):
         f, g = O.two_tone_bins(n, b)
-        ok &= abs(X[i, f] - n) < 1e-9 and abs(X[i, g] - n / 2) < 1e-9
+        ok &= abs(X[i, f] - n) < 1e-3 * n and abs(X[i, g] - n / 2) < 1e-3 * n
     owned = torch.zeros(world * per_gpu, dtype=torch.int32)
     owned[b0:b1] = 1
     dist.all_reduce(owned)  # test-only bookkeeping: who owns which transform
