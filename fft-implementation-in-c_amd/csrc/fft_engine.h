@@ -140,6 +140,7 @@ struct TeamDesc {
     int n_xcc = 0, log2seats = 0, n_teams = 0;  // XCDs x seats per XCD; n_teams = n_xcc << (log2seats - log2TS)
     bool defer = false;   // team_defer_kernel: the last row phase of a transform runs after the next one's column step
     bool asplit = false;  // column step on half-height, double-width tiles (128-byte row segments), fft_team.h ASPLIT
+    bool pair = false;    // team_defer_kernel PAIR: adjacent row tiles in phases (0,1) / (2,3), 2 CB-row result segments (fp32)
     int E = 0;  // elements per thread = stage radix (fp32: 16 -> 512 threads, 8 -> 1024 threads; fp64: 8)
     int data_bytes = 0, tables_elems = 0, smem_bytes = 0;
     int o_sb1 = 0, o_sa2 = 0, o_sb2 = 0, o_t0 = 0, o_t1 = 0, sa1_bits = 0, sa2_bits = 0, t0_bits = 0;
@@ -264,6 +265,7 @@ class Pow2Plan {
         make_twiddle_table<T>(part, n, 1ll << (log2n - d.t0_bits), 1ll << d.t0_bits);
         std::copy(part.begin(), part.end(), blob.begin() + d.o_t1);
         d.defer = d.NT == 4 && !d.asplit && rt->team_defer(SZ, log2n);
+        d.pair = d.defer && V == 2 && d.log2CB >= 1 && rt->team_pair(SZ, log2n);
         d.scratch_bytes = ((size_t)SZ << (log2TE + d.log2TS)) * (d.defer ? 3 : 2) * (size_t)d.n_teams;  // 2 (3) windows of TS tiles per team
         d.tables = (cpx<T>*)rt->dmalloc(blob.size() * SZ);
         d.scratch = (unsigned char*)rt->dmalloc(d.scratch_bytes);
@@ -292,7 +294,10 @@ class Pow2Plan {
         const long long grid = (long long)team.n_xcc << team.log2seats;
         constexpr int GEO = fftk::TeamGeo<T, LOG2N>::value;
         if (GEO == 0) return;
-        if (team.defer)
+        if (team.defer && team.pair && fftk::TeamPairBuilt<T, LOG2N>::value)
+            rt->launch_coresident(fftk::team_defer_kernel<T, 8 * V, (GEO ? GEO : 1), fftk::TeamPairBuilt<T, LOG2N>::value>, grid, team.nthreads,
+                                  (size_t)team.smem_bytes, tp);
+        else if (team.defer)
             rt->launch_coresident(fftk::team_defer_kernel<T, 8 * V, (GEO ? GEO : 1)>, grid, team.nthreads, (size_t)team.smem_bytes, tp);
         else if (fftk::TeamAsplitBuilt<T, LOG2N>::value && team.asplit)
             rt->launch_coresident(fftk::team_fft_kernel<T, 4, 8 * V, (GEO ? GEO : 1), fftk::TeamAsplitBuilt<T, LOG2N>::value>, grid,
@@ -304,7 +309,9 @@ class Pow2Plan {
     template <int NT>
     void launch_team_emu(const fftk::TeamParams<T>& tp) {
         const long long grid = (long long)team.n_xcc << team.log2seats;
-        if (NT == 4 && team.defer)
+        if (NT == 4 && team.defer && team.pair)
+            rt->launch_coresident(fftk::team_defer_kernel<T, 8 * V, 0, (V == 2)>, grid, team.nthreads, (size_t)team.smem_bytes, tp);
+        else if (NT == 4 && team.defer)
             rt->launch_coresident(fftk::team_defer_kernel<T, 8 * V, 0>, grid, team.nthreads, (size_t)team.smem_bytes, tp);
         else if (NT == 4 && team.asplit)
             rt->launch_coresident(fftk::team_fft_kernel<T, 4, 8 * V, 0, true>, grid, team.nthreads, (size_t)team.smem_bytes, tp);
@@ -328,7 +335,7 @@ class Pow2Plan {
 #if defined(FFT_EMU)
         return true;
 #else
-        return team.NT == 4 && built_geo() == FFT_TEAM_GEO(team.log2L1, team.log2L2, team.log2CA, team.log2CB, team.log2TS);
+        return team.NT == 4 && built_geo() == FFT_TEAM_GEO(team.log2L1, team.log2L2, team.log2CA, team.log2CB, team.log2TS);  // (team.pair without a PAIR instantiation runs the plain deferred kernel)
 #endif
     }
 
@@ -359,12 +366,15 @@ class Pow2Plan {
         tp.dma_split2 = dma_split2;
         static const int seat_rot = FFT_EXP_ENV("FFT_HIP_TEAM_SEAT_ROT") ? atoi(FFT_EXP_ENV("FFT_HIP_TEAM_SEAT_ROT")) : 0;
         tp.seat_rot = seat_rot;
-        static const int tile_rot = FFT_EXP_ENV("FFT_HIP_TEAM_TILE_ROT") ? atoi(FFT_EXP_ENV("FFT_HIP_TEAM_TILE_ROT")) : 4;
-        tp.tile_rot = tile_rot;
+        // measured (profiles/r2_ab_pair.txt): 4 for the plain kernels, 2 where the row tiles are paired
+        static const int tile_rot = FFT_EXP_ENV("FFT_HIP_TEAM_TILE_ROT") ? atoi(FFT_EXP_ENV("FFT_HIP_TEAM_TILE_ROT")) : -1;
+        tp.tile_rot = tile_rot >= 0 ? tile_rot : (team.pair ? 2 : 4);
         // column-tile DMA with the non-temporal bit (read once: the first lines to leave the L2, which keeps more of the
         // hand-over windows there): +1..3 % at every size; nt result stores and nt window loads measured even or worse
-        static const int nt_mask = FFT_EXP_ENV("FFT_HIP_TEAM_NT") ? atoi(FFT_EXP_ENV("FFT_HIP_TEAM_NT")) : 1;
-        tp.nt_mask = nt_mask;
+        // With paired row tiles (PAIR) a result store instruction writes whole 128-byte lines, so the result stream can be
+        // non-temporal too (as 64-byte halves it could not: the halves left the L2 one by one, WRITE 8.6 -> 10 GB): +3-5 %
+        static const int nt_mask = FFT_EXP_ENV("FFT_HIP_TEAM_NT") ? atoi(FFT_EXP_ENV("FFT_HIP_TEAM_NT")) : -1;
+        tp.nt_mask = nt_mask >= 0 ? nt_mask : (team.pair ? 3 : 1);
         static const int tune = FFT_EXP_ENV("FFT_HIP_TEAM_TUNE") ? atoi(FFT_EXP_ENV("FFT_HIP_TEAM_TUNE")) : 0;
         tp.tune = tune;
         tp.force_no_teams = team_force_fallback ? 1 : 0;  // test hook (fft_gpu_plan_set_option_hip): exercise the fallback on a healthy device

@@ -44,6 +44,10 @@ FFT_ROWS_LIST(FFT_EXTERN)
         }                                                                                            \
     } while (0)
 
+#ifndef FFT_TEAM_PAIR_DEFAULT
+#define FFT_TEAM_PAIR_DEFAULT 1
+#endif
+
 namespace {
 
 // resource counters (fft_gpu_debug_counters_hip): what a "cheap" repeated call must not move
@@ -137,6 +141,11 @@ struct HipRT {
     bool team_defer(int /*elem_bytes*/, int /*log2n*/) {
         static const int on = FFT_EXP_ENV("FFT_HIP_TEAM_DEFER") ? atoi(FFT_EXP_ENV("FFT_HIP_TEAM_DEFER")) : 1;
         return on != 0;
+    }
+    // team_defer_kernel PAIR (fft_team_defer.h): 128-byte result segments where the row tiles have only 8 rows
+    bool team_pair(int elem_bytes, int log2n) {
+        static const int on = FFT_EXP_ENV("FFT_HIP_TEAM_PAIR") ? atoi(FFT_EXP_ENV("FFT_HIP_TEAM_PAIR")) : FFT_TEAM_PAIR_DEFAULT;
+        return on && elem_bytes == 8 && (log2n == 19 || log2n == 20);
     }
     // 100 MHz wall clock.  Formation: 1 ms -- on a device shared with somebody else's kernel the launch gives up at once
     // (nothing touched) and the multi-pass plan queued behind it runs.  Team waits: 2 s, a deadlock breaker only: every

@@ -283,6 +283,61 @@ FFT_DEVICE void team_hand_over(unsigned char* sb, const cpx<T> (&y)[K], int n2, 
     }
 }
 
+// Which row tile of the row step does row k1 of the intermediate belong to?  L1 / CB blocks of CB rows = NT * TS tiles.
+//   plain : block bi = k1 / CB goes to phase bi / TS, seat bi % TS        (a seat's four tiles are L1 / 4 rows apart)
+//   PAIR  : blocks 2p and 2p + 1 go to the SAME seat (p % TS) in the two phases 2 (p / TS) and 2 (p / TS) + 1: a seat's
+//           tiles of phases (0, 1) and of (2, 3) are ADJACENT blocks of rows, so that it can write their results
+//           together as 2 CB-row = 128-byte segments (fp32, CB = 8) instead of two rounds of 64-byte ones.
+template <bool PAIR>
+FFT_DEVICE void team_row_dest(int k1, int log2CB, int log2TS, int& phase, int& seat, int& i) {
+    i = k1 & ((1 << log2CB) - 1);
+    const int bi = k1 >> log2CB;
+    if (PAIR) {
+        phase = ((bi >> (log2TS + 1)) << 1) | (bi & 1);
+        seat = (bi >> 1) & ((1 << log2TS) - 1);
+    } else {
+        phase = bi >> log2TS;
+        seat = bi & ((1 << log2TS) - 1);
+    }
+}
+// first row of the tile of (phase, seat)
+template <bool PAIR>
+FFT_DEVICE int team_tile_row0(int phase, int seat, int log2CB, int log2TS) {
+    if (PAIR) return (((((phase >> 1) << log2TS) + seat) << 1) | (phase & 1)) << log2CB;
+    return ((phase << log2TS) + seat) << log2CB;
+}
+
+// Hand over the K register slots slot0 .. slot0 + K - 1 of one column n2 (slot e = row k1 = r + TPC * e of the
+// intermediate): every value goes into the window of ITS phase (win_of(phase): the window's base, or NULL = not now)
+// at its receiver's row tile.  fp32: the lanes of rows k1, k1 + 1 pair up so that every store is 16 bytes.
+template <typename T, int K, bool PAIR, class WinOf>
+FFT_DEVICE void team_hand_over_rows(WinOf&& win_of, const cpx<T> (&y)[K], int slot0, int n2, int r, int log2TPC, int log2CB, int log2TS,
+                                    unsigned tile_bytes, int pair_mask) {
+    constexpr int SZ = (int)sizeof(cpx<T>);
+    if constexpr (vec16<T>::V == 2) {
+        const bool odd = (r & 1) != 0;
+        FFT_UNROLL
+        for (int q = 0; q < K / 2; q++) {
+            vec16<T> v;
+            pair_rows<T>(y[2 * q], y[2 * q + 1], odd, pair_mask, v);  // every lane takes part (cross-lane moves)
+            const int k1 = (r & ~1) + ((slot0 + 2 * q + (odd ? 1 : 0)) << log2TPC);  // even row of the pair
+            int phase, cp, i;
+            team_row_dest<PAIR>(k1, log2CB, log2TS, phase, cp, i);
+            unsigned char* sb = win_of(phase);
+            if (sb) *reinterpret_cast<vec16<T>*>(sb + (size_t)cp * tile_bytes + (((size_t)n2 << log2CB) + i) * SZ) = v;
+        }
+    } else {
+        FFT_UNROLL
+        for (int ee = 0; ee < K; ee++) {
+            const int k1 = r + ((slot0 + ee) << log2TPC);
+            int phase, cp, i;
+            team_row_dest<PAIR>(k1, log2CB, log2TS, phase, cp, i);
+            unsigned char* sb = win_of(phase);
+            if (sb) *reinterpret_cast<cpx<T>*>(sb + (size_t)cp * tile_bytes + (((size_t)n2 << log2CB) + i) * SZ) = y[ee];
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // The kernel.  Per transform a workgroup signals NT + 1 "arrivals" (generation numbers count up across transforms) on
 // its team's counter (NT == 4: every member waits for everybody's arrival g before its own arrival g + 1, so

@@ -21,9 +21,15 @@
 
 namespace fftk {
 
-template <typename T, int E, int GEO>
+// PAIR (fp32): a seat's row tiles of phases (0, 1) and of (2, 3) are adjacent blocks of CB rows (team_row_dest); the
+// results of the even phase wait in 2 * E registers and are written together with the odd phase's as 2 CB-row segments
+// -- 128 bytes at n = 2^19, 2^20, where CB = 8 rows are all that fit a 64 KiB tile.  A CU's store pipeline moves 128-byte
+// segments half again as fast as 64-byte ones (profiles/r1e_membench4: 22 vs 14 GB/s), and the row phases are bound by
+// their result stores.  The held results of phase 2 cross the next transform's column step (phase 3 is the deferred one).
+template <typename T, int E, int GEO, bool PAIR = false>
 FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E) team_defer_kernel(TeamParams<T> p) {
     constexpr int NT = 4;
+    static_assert(!PAIR || vec16<T>::V == 2, "paired result stores: fp32 only");
     constexpr int V16 = vec16<T>::V;
     constexpr int log2V16 = Log2<V16>::value;
     constexpr int log2E = Log2<E>::value;
@@ -32,6 +38,9 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
     constexpr int EP = E / NT;
     constexpr int NK = 2;
     constexpr int log2NT = 2;
+    // result stores a row phase leaves in flight when it closes (everything older must be complete): PAIR -- none after
+    // the even phase of a pair (its results wait in registers), twice as many after the odd one
+    constexpr int NRS_EVEN = PAIR ? 0 : NCH, NRS_ODD = PAIR ? 2 * NCH : NCH;
     FFT_DYN_SMEM(smem);
 
     const int tid_invariant = FFT_TID;
@@ -158,20 +167,31 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
     // chunks of a landing DMA issued from slot s of a tile with `total` slots: two halves from slots 0 and 1
     auto slot_i0 = [&](int s) __attribute__((always_inline)) { return s == 0 ? 0 : FFT_TEAM_DMA_FIRST(NCH); };
     auto slot_i1 = [&](int s, int total) __attribute__((always_inline)) { return s == 0 ? (total >= 2 ? FFT_TEAM_DMA_FIRST(NCH) : NCH) : NCH; };
-    // hand over phase ph (2 or 3) from the kept registers into window `sb`, all four column tiles
+    // hand over phase ph (2 or 3) from the kept registers into window `sb`, all four column tiles.  Which kept slots belong
+    // to phase ph follows from the row mapping (team_row_dest): plain -- the first EP kept slots are phase 2, the rest
+    // phase 3; PAIR -- a matter of the row's block parity (for n = 2^20: of the wave), every kept slot is looked at
     auto hand_over_kept = [&](unsigned char* sb, int ph, int rA, int jA) __attribute__((always_inline)) {
-        const bool third = (ph == 3);
         FFT_UNROLL
         for (int tt = 0; tt < NT; tt++) {
-            cpx<T> y[EP];
-            FFT_UNROLL
-            for (int ee = 0; ee < EP; ee++) {  // value by value (see pair_rows)
-                const cpx<T> a = keep[tt][ee], b3 = keep[tt][EP + ee];
-                y[ee] = mk<T>(third ? b3.re : a.re, third ? b3.im : a.im);
+            if constexpr (PAIR) {
+                cpx<T> y[NK * EP];
+                FFT_UNROLL
+                for (int k = 0; k < NK * EP; k++) y[k] = keep[tt][k];
+                team_hand_over_rows<T, NK * EP, true>([&](int phase) -> unsigned char* { return phase == ph ? sb : nullptr; }, y, 2 * EP,
+                                                      (column_block(tt) << log2CA) + jA, rA, log2TPCA, log2CB, log2TS, tile_bytes, 1 << log2CA);
+            } else {
+                const bool third = (ph == 3);
+                cpx<T> y[EP];
+                FFT_UNROLL
+                for (int ee = 0; ee < EP; ee++) {  // value by value (see pair_rows)
+                    const cpx<T> a = keep[tt][ee], b3 = keep[tt][EP + ee];
+                    y[ee] = mk<T>(third ? b3.re : a.re, third ? b3.im : a.im);
+                }
+                team_hand_over<T, EP>(sb, y, (column_block(tt) << log2CA) + jA, rA, log2TPCA, log2CB, tile_bytes, 1 << log2CA);
             }
-            team_hand_over<T, EP>(sb, y, (column_block(tt) << log2CA) + jA, rA, log2TPCA, log2CB, tile_bytes, 1 << log2CA);
         }
     };
+    vec16<T> vhold[PAIR ? E / 2 : 1];  // PAIR: the results of the even phase of a pair, until the odd phase stores both
     // one row phase: the tile has landed; stages with `traffic(s, total)` in their slots; transposed result store
     auto row_body = [&](cpx<T>* outb, int ph, auto&& traffic) __attribute__((always_inline)) {
         int tid = tid_invariant;
@@ -179,7 +199,7 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
         const int jB = tid & ((1 << log2CB) - 1), rB = tid >> log2CB;
         cpx<T> x[1][E][1];
         team_all_stages<T, E>(x, land, work, twB, rB, jB, log2CB, log2TPCB, log2L2, traffic, false);
-        const long long k1 = ((long long)ph << (log2L1 - log2NT)) + ((long long)c << log2CB);
+        const long long k1 = team_tile_row0<PAIR>(ph, c, log2CB, log2TS);
         if (p.inverse) {
             FFT_UNROLL
             for (int e = 0; e < E; e++) x[0][e][0] = cswap(x[0][e][0]);
@@ -188,7 +208,44 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
             FFT_UNROLL
             for (int e = 0; e < E; e++) x[0][e][0] = cscale(x[0][e][0], p.scale);
         }
-        if constexpr (V16 == 2) {
+        if constexpr (PAIR) {
+            const bool odd = (jB & 1) != 0;
+            if ((ph & 1) == 0) {  // even phase of a pair: nothing is stored yet
+                FFT_UNROLL
+                for (int q = 0; q < E / 2; q++) pair_rows<T>(x[0][2 * q][0], x[0][2 * q + 1][0], odd, 1, vhold[q]);
+            } else {
+                // Lane pair (e, o) = (jB even, jB + 1).  After pair_rows e holds rows (jB, jB + 1) of output line k2(2q), o of
+                // line k2(2q + 1) -- for the held tile A (rows 0 .. CB-1 of the pair) and for this tile B (rows CB .. 2CB-1).
+                // One more exchange (e's B piece <-> o's A piece) and every store instruction writes WHOLE 2 CB-row
+                // segments: first line k2(2q) [A from e | B from o], then line k2(2q + 1) [A from e | B from o].
+                const long long kpair = k1 - ((long long)1 << log2CB);  // row 0 of the pair's first tile
+                cpx<T>* const line0 = outb + ((long long)rB << log2L1) + kpair + (odd ? (1 << log2CB) + (jB & ~1) : jB);
+                const long long lstep = 1ll << (log2TPCB + log2L1);  // one slot further on
+                FFT_UNROLL
+                for (int q = 0; q < E / 2; q++) {
+                    vec16<T> vb;
+                    pair_rows<T>(x[0][2 * q][0], x[0][2 * q + 1][0], odd, 1, vb);
+                    const vec16<T> va = vhold[q];
+                    vec16<T> first, second;  // what this lane stores into line k2(2q) and into line k2(2q + 1)
+                    FFT_UNROLL
+                    for (int w = 0; w < 2; w++) {
+                        const T s_re = odd ? va.c[w].re : vb.c[w].re, s_im = odd ? va.c[w].im : vb.c[w].im;  // o sends its A, e its B
+                        const T r_re = FFT_XOR_EXCHANGE(s_re, 1, odd), r_im = FFT_XOR_EXCHANGE(s_im, 1, odd);
+                        first.c[w] = mk<T>(odd ? r_re : va.c[w].re, odd ? r_im : va.c[w].im);    // e: own A;  o: e's B
+                        second.c[w] = mk<T>(odd ? vb.c[w].re : r_re, odd ? vb.c[w].im : r_im);   // e: o's A;  o: own B
+                    }
+                    vec16<T>* const d0 = reinterpret_cast<vec16<T>*>(line0 + (long long)(2 * q) * lstep);
+                    vec16<T>* const d1 = reinterpret_cast<vec16<T>*>(line0 + (long long)(2 * q + 1) * lstep);
+                    if (p.nt_mask & 2) {
+                        FFT_STORE16_NT(d0, first);
+                        FFT_STORE16_NT(d1, second);
+                    } else {
+                        *d0 = first;
+                        *d1 = second;
+                    }
+                }
+            }
+        } else if constexpr (V16 == 2) {
             const bool odd = (jB & 1) != 0;
             vec16<T> v[E / 2];
             FFT_UNROLL
@@ -243,12 +300,20 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
                 team_interpass_twiddle<T, E>(x, tab + p.o_t0, tab + p.o_t1, p.t0_bits, (unsigned)rA * n2, n2 << log2TPCA);
             }
             if (t == 0 && it > 0) wait_all(G);  // S0 / S1 were last read by row tiles 2 / 1 of it-1 (X4 covers both)
-            FFT_UNROLL
-            for (int ph = 0; ph < 2; ph++) {
-                cpx<T> y[EP];
+            if constexpr (PAIR) {
+                cpx<T> y[2 * EP];
                 FFT_UNROLL
-                for (int ee = 0; ee < EP; ee++) y[ee] = x[0][ph * EP + ee][0];
-                team_hand_over<T, EP>(ph ? S1 : S0, y, (column_block(t) << log2CA) + jA, rA, log2TPCA, log2CB, tile_bytes, 1 << log2CA);
+                for (int ee = 0; ee < 2 * EP; ee++) y[ee] = x[0][ee][0];
+                team_hand_over_rows<T, 2 * EP, true>([&](int phase) -> unsigned char* { return phase ? S1 : S0; }, y, 0,
+                                                     (column_block(t) << log2CA) + jA, rA, log2TPCA, log2CB, log2TS, tile_bytes, 1 << log2CA);
+            } else {
+                FFT_UNROLL
+                for (int ph = 0; ph < 2; ph++) {
+                    cpx<T> y[EP];
+                    FFT_UNROLL
+                    for (int ee = 0; ee < EP; ee++) y[ee] = x[0][ph * EP + ee][0];
+                    team_hand_over<T, EP>(ph ? S1 : S0, y, (column_block(t) << log2CA) + jA, rA, log2TPCA, log2CB, tile_bytes, 1 << log2CA);
+                }
             }
             FFT_UNROLL
             for (int tt = 0; tt < NT; tt++) {
@@ -270,7 +335,7 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
                 if (s == 0) wait_all(G + 1);
                 dma_row_tile(S0, slot_i0(s), slot_i1(s, total));
             });
-            FFT_WAIT_VM_LE(NCH);  // everything but the deferred phase's result stores: row tile 0 has landed
+            FFT_WAIT_VM_LE(NRS_ODD);  // everything but the deferred phase's result stores: row tile 0 has landed
         } else {
             wait_all(G + 1);
             dma_row_tile(S0, 0, NCH);
@@ -287,7 +352,7 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
                 hand_over_kept(S0, 2, rA, jA);
             }
         });
-        FFT_WAIT_VM_LE(NCH);
+        FFT_WAIT_VM_LE(NRS_EVEN);
         FFT_SYNC_LDS();
         arrive(G + 3);  // X3
         row_body(outb, 1, [&](int s, int total) {
@@ -297,7 +362,7 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
             // S2 was last read by the deferred row tile, landed everywhere since X1
             if (s == (total >= 2 ? 1 : 0)) hand_over_kept(S2, 3, rA, jA);
         });
-        FFT_WAIT_VM_LE(NCH);
+        FFT_WAIT_VM_LE(NRS_ODD);
         FFT_SYNC_LDS();
         arrive(G + 4);  // X4
         row_body(outb, 2, [&](int s, int total) {

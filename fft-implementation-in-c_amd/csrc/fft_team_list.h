@@ -26,4 +26,12 @@ struct TeamAsplitBuilt {
     static constexpr bool value = false;
 };
 template <> struct TeamAsplitBuilt<float, 20> { static constexpr bool value = true; };
+// sizes whose PAIR variant of team_defer_kernel (paired row tiles, 128-byte result segments) is instantiated: the fp32
+// geometries with CB = 8 rows per row tile
+template <typename T, int LOG2N>
+struct TeamPairBuilt {
+    static constexpr bool value = false;
+};
+template <> struct TeamPairBuilt<float, 20> { static constexpr bool value = true; };
+template <> struct TeamPairBuilt<float, 19> { static constexpr bool value = true; };
 }  // namespace fftk

@@ -169,6 +169,29 @@ def test_team_kernel(n, batch, dtype, log2seats, n_xcc, threads, lds, tiles, pla
             assert rel(y, oracle(x, d)) < TOL[dtype], (n, d, inplace)
 
 
+@pytest.mark.parametrize("n,batch,log2seats,n_xcc,threads,lds,l1", [
+    (4096, 5, 2, 2, 16, 16384, None),     # 64 x 64, CB = 4: a team of 4; block parity = a bit of the row-in-thread index
+    (2048, 9, 2, 2, 16, 8192, None),      # 32 x 64, two teams of 2 per "XCD"
+    (1024, 11, 3, 2, 8, 4096, None),      # 32 x 32, teams of 2, ragged batch
+    (1 << 14, 5, 2, 2, 64, 65536, 5),     # 32 x 512: three-stage rows
+    (1 << 16, 3, 3, 2, 128, 1 << 17, 6),  # 64 x 1024: the production stage sequence 16 x 16 x 4 with the bank swizzle
+    (1 << 14, 6, 2, 2, 64, 65536, 8),     # 256 x 64: TPCA = 16 > CB = 4 ... every kind of slot <-> phase relation
+])
+def test_team_kernel_paired_row_tiles(n, batch, log2seats, n_xcc, threads, lds, l1, monkeypatch):
+    """team_defer_kernel PAIR: a seat's row tiles of phases (0, 1) and (2, 3) are adjacent blocks of rows, the even phase's
+    results wait in registers (phase 2's across the next transform's column step) and both are written as double-width
+    segments by the odd phase."""
+    monkeypatch.setenv("FFT_EMU_TEAM_PAIR", "1")
+    if l1:
+        monkeypatch.setenv("FFT_HIP_TEAM_L1", str(l1))
+    x = O.gen_lcg(n, 17, batch).astype(np.complex64)
+    for d in (-1, 1):
+        for inplace in (False, True):
+            y, info = E.emu_fft_team(x, d, log2seats=log2seats, n_xcc=n_xcc, threads=threads, lds_budget=lds, inplace=inplace)
+            assert info[0] // 100 == 4 and info[6] & 4, "the paired kernel was not planned"
+            assert rel(y, oracle(x, d)) < TOL[np.complex64], (n, d, inplace)
+
+
 def test_team_kernel_fallback_when_teams_cannot_form():
     """Workgroup 0 reports the wrong XCD: no launch yields full teams, the kernel must give up before touching
     anything and the two-pass schedule queued behind it must produce the result (also in place)."""

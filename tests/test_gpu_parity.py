@@ -643,12 +643,12 @@ def test_team_kernels_of_two_plans_on_two_streams(gpu_lib, monkeypatch):
         b.free()
 
 
-@pytest.mark.parametrize("defer,nt", [("0", "0"), ("1", "0"), ("1", "7"), ("0", "7")])
-def test_team_kernel_forced_variants(gpu_lib, defer, nt):
+@pytest.mark.parametrize("defer,nt,pair", [("0", "0", "1"), ("1", "0", "1"), ("1", "7", "1"), ("0", "7", "1"), ("1", "0", "0"), ("1", "3", "0")])
+def test_team_kernel_forced_variants(gpu_lib, defer, nt, pair):
     """Both team kernels at every kind of size, whatever the per-size default is: FFT_HIP_TEAM_DEFER=0 team_fft_kernel,
     =1 team_defer_kernel (the deferred row phase), with the default cache-policy bits off (FFT_HIP_TEAM_NT=0) and all
-    on (7: non-temporal column-tile DMA, result stores and window loads).  The variables are read once per process,
-    hence the fresh one."""
+    on (7: non-temporal column-tile DMA, result stores and window loads), with and without the paired row tiles of
+    fp32 n = 2^19, 2^20 (FFT_HIP_TEAM_PAIR; the default is on).  The variables are read once per process, hence the fresh one."""
     import subprocess
     import sys
     code = (
@@ -656,7 +656,7 @@ def test_team_kernel_forced_variants(gpu_lib, defer, nt):
         "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
         "import fftlib, oracle_lib as O\n"
         "fftlib.init()\n"
-        "for log2n, dt in ((20, np.complex64), (18, np.complex64), (17, np.complex128), (18, np.complex128)):\n"
+        "for log2n, dt in ((20, np.complex64), (19, np.complex64), (18, np.complex64), (17, np.complex128), (18, np.complex128)):\n"
         "    n, batch = 1 << log2n, 70\n"
         "    x = O.gen_lcg(n, 33, batch).astype(dt)\n"
         "    buf = fftlib.DeviceBuffer(x.nbytes)\n"
@@ -674,7 +674,7 @@ def test_team_kernel_forced_variants(gpu_lib, defer, nt):
         "print('ok')\n"
     ) % (os.path.join(ROOT, "fft-implementation-in-c_amd"), os.path.join(ROOT, "tests"))
     # kernel-variant switches exist only in the -DFFT_EXPERIMENTS build of the library
-    env = dict(os.environ, FFT_HIP_TEAM="2", FFT_HIP_TEAM_DEFER=defer, FFT_HIP_TEAM_NT=nt,
+    env = dict(os.environ, FFT_HIP_TEAM="2", FFT_HIP_TEAM_DEFER=defer, FFT_HIP_TEAM_NT=nt, FFT_HIP_TEAM_PAIR=pair,
                FFT_LIB_PATH=os.path.join(ROOT, "fft-implementation-in-c_amd", "libfft_mi355x_exp.so"))
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr

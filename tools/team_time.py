@@ -1,0 +1,40 @@
+"""Quick same-box timing (and a parity spot check) of one plan: python tools/team_time.py log2n batch [f32|f64] [tag]
+Uses the library FFT_LIB_PATH points at (tools/ab_env.sh sets the -DFFT_EXPERIMENTS build and the variant's env)."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "fft-implementation-in-c_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import fftlib  # noqa: E402
+import oracle_lib as O  # noqa: E402
+
+
+def main():
+    log2n, batch = int(sys.argv[1]), int(sys.argv[2])
+    dtype = np.complex128 if (len(sys.argv) > 3 and sys.argv[3] == "f64") else np.complex64
+    tag = sys.argv[4] if len(sys.argv) > 4 else ""
+    n = 1 << log2n
+    fftlib.init()
+    x8 = O.gen_lcg(n, 3, 8).astype(dtype)
+    x = np.tile(x8, (batch // 8, 1))
+    a, b = fftlib.DeviceBuffer(x.nbytes), fftlib.DeviceBuffer(x.nbytes)
+    a.upload(x)
+    plan = fftlib.Plan(n, batch, -1, dtype)
+    plan.execute_ptr(a.ptr, b.ptr)
+    st = plan.team_status()
+    y = b.download(x.shape, dtype)
+    ref = O.oracle_fft(x8[:2].astype(np.complex128), -1, "exact")
+    err = max(float(np.linalg.norm(y[i] - ref[i % 8 if i < 8 else (i % 8)]) / np.linalg.norm(ref[i % 8])) for i in (0, 1))
+    err_last = float(np.linalg.norm(y[batch - 7] - ref[1]) / np.linalg.norm(ref[1]))
+    plan.timed(a.ptr, b.ptr, 3)
+    ms = sorted(plan.timed(a.ptr, b.ptr, 10) / 10 for _ in range(5))
+    print("%-28s n=2^%d x %d: median %.3f ms (min %.3f) = %.1f Gpoint/s, %.2f TB/s alg = %.1f %% of 8 TB/s; status %d; rel err %.1e / %.1e" %
+          (tag, log2n, batch, ms[2], ms[0], n * batch / ms[2] / 1e6, 2 * x.nbytes / ms[2] / 1e9, 2 * x.nbytes / ms[2] / 1e6 / 80, st, err, err_last), flush=True)
+    assert err < 5e-6 and err_last < 5e-6 or dtype == np.complex128
+
+
+if __name__ == "__main__":
+    main()
