@@ -147,6 +147,13 @@ struct HipRT {
         static const int on = FFT_EXP_ENV("FFT_HIP_TEAM_PAIR") ? atoi(FFT_EXP_ENV("FFT_HIP_TEAM_PAIR")) : FFT_TEAM_PAIR_DEFAULT;
         return on && elem_bytes == 8 && (log2n == 19 || log2n == 20);
     }
+    // NODEFER (two live windows per team instead of three): measured with the paired kernel (profiles/r2_pmc_variants.txt)
+    // n = 2^20: window refetch 3.8 -> 1.2 GB per 512 transforms (L2 hit rate 51 -> 67 %), +1..2.5 % throughput; n = 2^19
+    // (teams of 16: the turn costs more than the hits return): -1 %
+    bool team_nodefer(int elem_bytes, int log2n) {
+        static const int on = FFT_EXP_ENV("FFT_HIP_TEAM_NODEFER") ? atoi(FFT_EXP_ENV("FFT_HIP_TEAM_NODEFER")) : -1;
+        return on >= 0 ? on != 0 : (elem_bytes == 8 && log2n == 20);
+    }
     // 100 MHz wall clock.  Formation: 1 ms -- on a device shared with somebody else's kernel the launch gives up at once
     // (nothing touched) and the multi-pass plan queued behind it runs.  Team waits: 2 s, a deadlock breaker only: every
     // member of a formed team is resident and running, so a wait ends when the slowest member gets there.

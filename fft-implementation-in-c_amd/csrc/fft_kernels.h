@@ -143,6 +143,14 @@ struct StageTw {
 // General form: the inputs are read from the image at `smem_rd`, the outputs written to the image at `smem`
 // (the same image in the tile kernels; the team kernel's first stage reads the LDS-DMA landing buffer and writes
 // the work buffer).  `after_read` runs once every wave has finished reading `smem_rd` (not called when first).
+// the two workgroup barriers of a stage exchange.  TIMING EXPERIMENT ONLY (-DFFT_EXPERIMENTS -DFFT_ABLATE_STAGE_BARRIERS):
+// without the s_barrier the waves of a workgroup drift apart -- results are garbage, but the launch time shows what a
+// schedule whose exchanges need no workgroup barrier could gain (the vector-ALU and LDS phases of different waves overlap)
+#if defined(FFT_EXPERIMENTS) && defined(FFT_ABLATE_STAGE_BARRIERS) && !defined(FFT_EMU)
+#define FFT_STAGE_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#else
+#define FFT_STAGE_SYNC() FFT_SYNC_LDS()
+#endif
 struct StageNoHook {
     FFT_DEVICE void operator()() const {}
 };
@@ -211,7 +219,13 @@ FFT_DEVICE void stockham_stage_rw(cpx<T> (&x)[H][E][V], const unsigned char* sme
     // reads go out in batches of TB: the first batch BEFORE the butterflies (it lands under their arithmetic), batch b + 1
     // before the multiplies of batch b.  (Two-level tables: both factors are read, the product is formed at use.)
     // Only where the register budget has room for it (SWZ bit 2: the team kernels, two waves per SIMD).
-    constexpr bool PIPE_TW = (SWZ & 4) != 0;
+    // SWZ bit 3 (team kernels): the R - 1 output twiddles of a butterfly are the POWERS of its first one, W^(tq k) = w1^k.
+    // One table read (w1) and R - 2 complex products by repeated squaring / products at most log2 R deep, instead of
+    // R - 1 table reads with their index arithmetic: the LDS pipe (two waves per SIMD in lock step: its time adds to the
+    // vector ALU's) loses 14 of 15 reads per stage, and the reads it loses are the bank-conflicted ones.  Costs
+    // rounding: each twiddle carries up to log2 R products (rel. error of a transform 1.3e-7 -> ~4e-7 in fp32).
+    constexpr bool TREE_TW = (SWZ & 8) != 0;
+    constexpr bool PIPE_TW = (SWZ & 4) != 0 && !TREE_TW;
     constexpr int NTW = PIPE_TW ? G * (R - 1) : 0;
 #ifndef FFT_TW_BATCH
 #define FFT_TW_BATCH 4
@@ -257,8 +271,30 @@ FFT_DEVICE void stockham_stage_rw(cpx<T> (&x)[H][E][V], const unsigned char* sme
         }
     }
 
+    if (!last && TREE_TW) {
+        FFT_UNROLL
+        for (int m = 0; m < G; m++) {
+            const int u = r + (m << log2TPC);
+            const int q = u & Li_mask;
+            cpx<T> pw[R];  // pw[k] = w1^k
+            pw[1] = tw.get(q << log2P);
+            FFT_UNROLL
+            for (int k = 2; k < R; k++) {
+                const int hb = 1 << (31 - __builtin_clz((unsigned)k));  // highest set bit (k is a compile-time constant once unrolled)
+                pw[k] = (k == hb) ? cmul(pw[k >> 1], pw[k >> 1]) : cmul(pw[hb], pw[k - hb]);
+            }
+            FFT_UNROLL
+            for (int k = 1; k < R; k++) {
+                FFT_UNROLL
+                for (int h = 0; h < H; h++) {
+                    FFT_UNROLL
+                    for (int vv = 0; vv < V; vv++) x[h][m + G * k][vv] = cmul(x[h][m + G * k][vv], pw[k]);
+                }
+            }
+        }
+    }
     if (!last) {
-        if (!PIPE_TW) {
+        if (!PIPE_TW && !TREE_TW) {
             FFT_UNROLL
             for (int m = 0; m < G; m++) {
                 const int u = r + (m << log2TPC);
@@ -294,7 +330,7 @@ FFT_DEVICE void stockham_stage_rw(cpx<T> (&x)[H][E][V], const unsigned char* sme
             FFT_SCHED_BARRIER();
         }
         if (!first) {
-            FFT_SYNC_LDS();  // everyone has finished reading the previous exchange
+            FFT_STAGE_SYNC();  // everyone has finished reading the previous exchange
             after_read();
         }
         FFT_UNROLL
@@ -315,7 +351,7 @@ FFT_DEVICE void stockham_stage_rw(cpx<T> (&x)[H][E][V], const unsigned char* sme
                 }
             }
         }
-        FFT_SYNC_LDS();
+        FFT_STAGE_SYNC();
     }
     log2Lprev = log2Li;
     log2P += log2R;

@@ -167,6 +167,11 @@ FFT_DEVICE void team_report_timeout(const TeamParams<T>& p) {
     FFT_ATOMIC_ADD_AGENT(&p.sticky[TEAM_STICKY_TIMEOUTS], 1u);
 }
 
+// twiddles by powers (stockham_stage_rw SWZ bit 3, team_interpass_twiddle): build switch for same-box A/B
+#ifndef FFT_TEAM_TW_TREE
+#define FFT_TEAM_TW_TREE 1
+#endif
+
 #define FFT_TEAM_GEO(l1, l2, ca, cb, ts) ((l1) | ((l2) << 5) | ((ca) << 10) | ((cb) << 15) | ((ts) << 20))
 
 // All Stockham stages of one tile whose samples sit in the LDS-DMA landing image `land` ([element][column], the
@@ -183,10 +188,19 @@ struct StageHookAt {
     FFT_DEVICE void operator()() const { hook(s, total); }
 };
 
-template <typename T, int E, class Hook>
+// which geometries build their twiddles as powers (FFT_TEAM_TW_TREE): fp32 from n = 2^18 up (measured, profiles/r2_ab_tree.txt:
+// 2^20 +7 %, 2^19 +1.4 %, 2^18 +0.8 %, 2^16 -1.4 %); fp64 keeps its table reads (rounding budget 1e-11 in the tests);
+// GEO = 0 (the emulation's generic geometry) exercises the power path
+template <typename T, int GEO>
+struct TeamTwTree {
+    static constexpr bool value = FFT_TEAM_TW_TREE && sizeof(T) == 4 && (GEO == 0 || ((GEO & 31) + ((GEO >> 5) & 31)) >= 18);
+};
+
+template <typename T, int E, bool TREE = (FFT_TEAM_TW_TREE && sizeof(T) == 4), class Hook>
 FFT_DEVICE void team_all_stages(cpx<T> (&x)[1][E][1], const unsigned char* land, unsigned char* work, const StageTw<T>& tw,
                                 int r, int j, int log2J, int log2TPC, int log2L, Hook&& hook, bool swap_in) {
     constexpr int log2E = Log2<E>::value;
+    constexpr int TWB = TREE ? 8 : 0;  // stage twiddles by powers
     int log2Lprev = log2L, log2P = 0;
     const int n_full = log2L / log2E;
     const int rem = log2L - n_full * log2E;
@@ -197,11 +211,11 @@ FFT_DEVICE void team_all_stages(cpx<T> (&x)[1][E][1], const unsigned char* land,
     for (int s = 0; s < n_full; s++) {
         StageHookAt<Hook> h{hook, s, total};
         if (swz && s == n_full - 1)
-            stockham_stage_rw<T, E, E, 1, 1, 2 | 4>(x, s == 0 ? land : work, work, 0, tw, r, j, log2J, log2TPC, log2Lprev, log2P,
-                                                false, s == total - 1, h, s == 0 && swap_in);
+            stockham_stage_rw<T, E, E, 1, 1, 2 | 4 | TWB>(x, s == 0 ? land : work, work, 0, tw, r, j, log2J, log2TPC, log2Lprev, log2P,
+                                                      false, s == total - 1, h, s == 0 && swap_in);
         else
-            stockham_stage_rw<T, E, E, 1, 1, 4>(x, s == 0 ? land : work, work, 0, tw, r, j, log2J, log2TPC, log2Lprev, log2P, false,
-                                                s == total - 1, h, s == 0 && swap_in);
+            stockham_stage_rw<T, E, E, 1, 1, 4 | TWB>(x, s == 0 ? land : work, work, 0, tw, r, j, log2J, log2TPC, log2Lprev, log2P, false,
+                                                  s == total - 1, h, s == 0 && swap_in);
     }
     // the remaining stage is always the last one: no exchange, no hook
     if (rem == 1) stockham_stage_rw<T, E, 2, 1, 1>(x, work, work, 0, tw, r, j, log2J, log2TPC, log2Lprev, log2P, false, true, StageNoHook());
@@ -217,11 +231,28 @@ FFT_DEVICE void team_all_stages(cpx<T> (&x)[1][E][1], const unsigned char* land,
 // x[e] *= W_n^(m_start + e * m_step) from the two-level LDS table (t0: low t0_bits of the exponent, t1: the rest).
 // The table reads of FOUR slots are issued together and then consumed: left to itself the compiler emits read, read,
 // wait, multiply per slot, i.e. sixteen LDS round trips in a row on the critical path of every column tile.
-template <typename T, int E>
+template <typename T, int E, bool TREE = (FFT_TEAM_TW_TREE && sizeof(T) == 4)>
 FFT_DEVICE void team_interpass_twiddle(cpx<T> (&x)[1][E][1], const cpx<T>* t0, const cpx<T>* t1, int t0_bits, unsigned m_start,
                                        unsigned m_step) {
     constexpr int B = 4;
     const unsigned m0 = (1u << t0_bits) - 1u;
+    if constexpr (TREE) {
+        // W^(m_start + e m_step) = base * step^e: four table reads (base and step, two-level each), then step^2, ^4, ^8 by
+        // squaring and w[e | bit] = w[e] * step^bit -- 18 products at most 4 deep instead of 32 reads and their index arithmetic
+        const cpx<T> base = cmul(t0[m_start & m0], t1[m_start >> t0_bits]);
+        cpx<T> sp = cmul(t0[m_step & m0], t1[m_step >> t0_bits]);
+        cpx<T> w[E];
+        w[0] = base;
+        FFT_UNROLL
+        for (int bit = 1; bit < E; bit <<= 1) {
+            FFT_UNROLL
+            for (int e = 0; e < bit; e++) w[e | bit] = cmul(w[e], sp);
+            sp = cmul(sp, sp);
+        }
+        FFT_UNROLL
+        for (int e = 0; e < E; e++) x[0][e][0] = cmul(x[0][e][0], w[e]);
+        return;
+    }
     FFT_UNROLL
     for (int e0 = 0; e0 < E; e0 += B) {
         cpx<T> a[B], b[B];

@@ -26,9 +26,13 @@ namespace fftk {
 // -- 128 bytes at n = 2^19, 2^20, where CB = 8 rows are all that fit a 64 KiB tile.  A CU's store pipeline moves 128-byte
 // segments half again as fast as 64-byte ones (profiles/r1e_membench4: 22 vs 14 GB/s), and the row phases are bound by
 // their result stores.  The held results of phase 2 cross the next transform's column step (phase 3 is the deferred one).
-template <typename T, int E, int GEO, bool PAIR = false>
+// NODEFER: the same kernel WITHOUT the deferral -- phase 3 runs right after phase 2 and is handed over into S1 (free
+// once row tile 1 has been read), so a team has TWO live windows instead of three (4 MiB per XCD instead of 6 against
+// the 4 MiB L2), at the price of the idle turn the deferral fills; five arrivals per transform (X5: row tile 3 landed).
+template <typename T, int E, int GEO, bool PAIR = false, bool NODEFER = false>
 FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E) team_defer_kernel(TeamParams<T> p) {
     constexpr int NT = 4;
+    constexpr bool TREE = TeamTwTree<T, GEO>::value;
     static_assert(!PAIR || vec16<T>::V == 2, "paired result stores: fp32 only");
     constexpr int V16 = vec16<T>::V;
     constexpr int log2V16 = Log2<V16>::value;
@@ -198,7 +202,7 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
         FFT_OPAQUE(tid);
         const int jB = tid & ((1 << log2CB) - 1), rB = tid >> log2CB;
         cpx<T> x[1][E][1];
-        team_all_stages<T, E>(x, land, work, twB, rB, jB, log2CB, log2TPCB, log2L2, traffic, false);
+        team_all_stages<T, E, TREE>(x, land, work, twB, rB, jB, log2CB, log2TPCB, log2L2, traffic, false);
         const long long k1 = team_tile_row0<PAIR>(ph, c, log2CB, log2TS);
         if (p.inverse) {
             FFT_UNROLL
@@ -273,7 +277,7 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
     for (int it = 0; it < M; it++) {
         const cpx<T>* inb = in_of(it);
         cpx<T>* outb = out_of(it);
-        const int G = 4 * it;  // this transform's arrivals are G + 1 .. G + 4
+        const int G = (NODEFER ? 5 : 4) * it;  // this transform's arrivals are G + 1 .. G + 4 (NODEFER: .. G + 5)
         int tid = tid_invariant;
         FFT_OPAQUE(tid);
         const int jA = tid & ((1 << log2CA) - 1), rA = tid >> log2CA;
@@ -286,18 +290,18 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
             cpx<T> x[1][E][1];
             FFT_WAIT_VM0();
             FFT_SYNC_LDS();
-            team_all_stages<T, E>(x, land, work, twA, rA, jA, log2CA, log2TPCA, log2L1, [&](int s, int total) {
+            team_all_stages<T, E, TREE>(x, land, work, twA, rA, jA, log2CA, log2TPCA, log2L1, [&](int s, int total) {
                 if (s > 1) return;
                 if (t + 1 < NT) {
                     dma_column_tile(inb, t + 1, slot_i0(s), slot_i1(s, total));
-                } else if (it > 0) {
+                } else if (it > 0 && !NODEFER) {
                     if (s == 0) wait_all(G);  // X4 of it-1: everybody's hand-over of its phase 3 is in L2
                     dma_row_tile(S2, slot_i0(s), slot_i1(s, total));
                 }
             }, p.inverse != 0);
             {
                 const unsigned n2 = (unsigned)(column_block(t) << log2CA) + (unsigned)jA;
-                team_interpass_twiddle<T, E>(x, tab + p.o_t0, tab + p.o_t1, p.t0_bits, (unsigned)rA * n2, n2 << log2TPCA);
+                team_interpass_twiddle<T, E, TREE>(x, tab + p.o_t0, tab + p.o_t1, p.t0_bits, (unsigned)rA * n2, n2 << log2TPCA);
             }
             if (t == 0 && it > 0) wait_all(G);  // S0 / S1 were last read by row tiles 2 / 1 of it-1 (X4 covers both)
             if constexpr (PAIR) {
@@ -329,7 +333,7 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
         arrive(G + 1);  // X1
 
         // ================= the turn: the deferred phase 3 of it-1 runs while X1 spreads and row tile 0 makes its trip
-        if (it > 0) {
+        if (it > 0 && !NODEFER) {
             row_body(out_of(it - 1), 3, [&](int s, int total) {
                 if (s > 1) return;
                 if (s == 0) wait_all(G + 1);
@@ -360,25 +364,36 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
             if (s == 0) wait_all(G + 3);
             dma_row_tile(S0, slot_i0(s), slot_i1(s, total));
             // S2 was last read by the deferred row tile, landed everywhere since X1
-            if (s == (total >= 2 ? 1 : 0)) hand_over_kept(S2, 3, rA, jA);
+            if (s == (total >= 2 ? 1 : 0)) hand_over_kept(NODEFER ? S1 : S2, 3, rA, jA);  // NODEFER: S1's row tile 1 has landed everywhere (X3)
         });
         FFT_WAIT_VM_LE(NRS_ODD);
         FFT_SYNC_LDS();
         arrive(G + 4);  // X4
         row_body(outb, 2, [&](int s, int total) {
             if (s > 1) return;
-            if (it + 1 < M) {
+            if (it + 1 < M && !NODEFER) {
                 dma_column_tile(in_of(it + 1), 0, slot_i0(s), slot_i1(s, total));
-            } else {  // the last transform fetches its own phase 3 right away
+            } else {  // the last transform (NODEFER: every transform) fetches its own phase 3 right away
                 if (s == 0) wait_all(G + 4);
-                dma_row_tile(S2, slot_i0(s), slot_i1(s, total));
+                dma_row_tile(NODEFER ? S1 : S2, slot_i0(s), slot_i1(s, total));
             }
         });
+        if constexpr (NODEFER) {
+            FFT_WAIT_VM_LE(NRS_EVEN);  // row tile 3 has landed
+            FFT_SYNC_LDS();
+            arrive(G + 5);  // X5: S0 / S1 may be rewritten by the next column step once everybody is here
+            row_body(outb, 3, [&](int s, int total) {
+                if (s > 1) return;
+                if (it + 1 < M) dma_column_tile(in_of(it + 1), 0, slot_i0(s), slot_i1(s, total));
+            });
+        }
     }
     // ================= phase 3 of the last transform
-    FFT_WAIT_VM0();
-    FFT_SYNC_LDS();
-    row_body(out_of(M - 1), 3, [&](int, int) {});
+    if constexpr (!NODEFER) {
+        FFT_WAIT_VM0();
+        FFT_SYNC_LDS();
+        row_body(out_of(M - 1), 3, [&](int, int) {});
+    }
 }
 
 }  // namespace fftk

