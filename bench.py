@@ -321,7 +321,7 @@ def main():
     lib = fftlib.init()
     plan = fftlib.Plan(n, batch, fftlib.FFT_FORWARD, npdtype, fftlib.ALGO_NAMES[args.algo])
     stream = torch.cuda.current_stream(device)
-    plan.set_stream(stream.cuda_stream)
+    plan.set_stream(stream.cuda_stream or fftlib.HIP_STREAM_LEGACY)  # handle 0 (torch's default stream) would mean "the plan's own stream"
     info = plan.info()
 
     b_first, b_last = shard_range(rank, world, batch)
@@ -493,7 +493,7 @@ def main():
                 torch.cuda.empty_cache()
                 n2, b2 = 1 << 19, 256
                 p2 = fftlib.Plan(n2, b2, fftlib.FFT_FORWARD, np.complex128)
-                p2.set_stream(stream.cuda_stream)
+                p2.set_stream(stream.cuda_stream or fftlib.HIP_STREAM_LEGACY)
                 x2 = make_input(torch, n2, b2, "f64", 0, device)
                 y2 = torch.empty_like(x2)
                 p2.timed(x2.data_ptr(), y2.data_ptr(), 2)

@@ -106,7 +106,9 @@ def engine_local_fft(t, direction):
     key = (n, batch, direction, dt, t.device.index)
     if key not in _plans:
         p = fftlib.Plan(n, batch, direction, dt)
-        p.set_stream(torch.cuda.current_stream(t.device).cuda_stream)
+        # torch's default stream has handle 0, which the C ABI reads as "the plan's own stream": name the legacy default
+        # stream explicitly (hipStreamLegacy = 1), or the transform would race with torch's kernels around it
+        p.set_stream(torch.cuda.current_stream(t.device).cuda_stream or fftlib.HIP_STREAM_LEGACY)
         _plans[key] = p
     out = torch.empty_like(t)
     _plans[key].execute_ptr(t.data_ptr(), out.data_ptr())

@@ -21,6 +21,7 @@ PREC_F32 = 1
 ALGO_AUTO, ALGO_RADIX2, ALGO_RADIX4, ALGO_SPLIT_RADIX, ALGO_RADIX2_GLOBAL, ALGO_BLUESTEIN, ALGO_RADIX2_SHFL = range(7)
 ALGO_NAMES = {"auto": 0, "radix2": 1, "radix4": 2, "split_radix": 3, "radix2_global": 4, "bluestein": 5, "radix2_shfl": 6}
 FFT_PREFER_GPU = 1 << 9
+HIP_STREAM_LEGACY = 1  # hipStreamLegacy: the NULL / default stream named explicitly (fft_gpu_plan_set_stream: NULL = the plan's own)
 
 
 class PlanInfo(C.Structure):

@@ -141,7 +141,9 @@ int fft_gpu_fused_out_len_hip(fft_gpu_plan_t plan); /* elements per output row (
  * d_out: [batch][out_len]; sample_rate scales FFT_GPU_FUSED_PSD only */
 int fft_gpu_execute_fused_hip(fft_gpu_plan_t plan, const void* d_x, const void* d_y, void* d_out, double sample_rate);
 int fft_gpu_plan_info_hip(fft_gpu_plan_t plan, fft_gpu_plan_info_t* info);
-int fft_gpu_plan_set_stream_hip(fft_gpu_plan_t plan, void* hip_stream); /* NULL = the plan's own stream */
+/* NULL = the plan's own (non-blocking) stream.  A caller that works on HIP's default stream -- PyTorch's default stream
+ * has the handle 0 -- names it explicitly: (void*)1 = hipStreamLegacy, or its work and the plan's are not ordered. */
+int fft_gpu_plan_set_stream_hip(fft_gpu_plan_t plan, void* hip_stream);
 int fft_gpu_execute_ptr_hip(fft_gpu_plan_t plan, const void* d_in, void* d_out); /* async on the plan's stream */
 int fft_gpu_plan_sync_hip(fft_gpu_plan_t plan);
 int fft_gpu_plan_set_option_hip(fft_gpu_plan_t plan, fft_gpu_plan_option_t option, int value);

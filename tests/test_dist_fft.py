@@ -90,10 +90,12 @@ def test_split_is_a_valid_factorisation():
         _split(1 << 5, 8)
 
 
-@pytest.mark.gpu
-def test_one_transform_through_the_engine_on_the_device(gpu_lib):
-    import torch
-    sys.path.insert(0, os.path.join(ROOT, "fft-implementation-in-c_amd"))
+GPU_WORKER = textwrap.dedent('''
+    import os, sys
+    import numpy as np
+    import torch                      # first: the process then has ONE HIP runtime (torch's), which the library shares
+    sys.path.insert(0, os.path.join(%(root)r, "tests"))
+    sys.path.insert(0, os.path.join(%(root)r, "fft-implementation-in-c_amd"))
     import oracle_lib as O
     from dist_fft import DistributedFFT1D, engine_local_fft
     for n, dtype in ((1 << 22, np.complex64), (1 << 20, np.complex128)):
@@ -106,3 +108,15 @@ def test_one_transform_through_the_engine_on_the_device(gpu_lib):
             ref = O.oracle_fft(x.astype(np.complex128), d, "exact")
             err = float(np.linalg.norm(y.cpu().numpy() - ref) / np.linalg.norm(ref))
             assert err < (3e-6 if dtype == np.complex64 else 1e-11), (n, d, err)
+    print("ok")
+''')
+
+
+@pytest.mark.gpu
+def test_one_transform_through_the_engine_on_the_device(tmp_path):
+    """World 1 on the device: the all-to-alls degenerate, every local batched transform runs through the C ABI on torch's
+    stream.  In a process of its own that imports torch BEFORE the library (as bench.py does)."""
+    script = tmp_path / "gpu_worker.py"
+    script.write_text(GPU_WORKER % {"root": ROOT})
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr[-3000:]
