@@ -29,6 +29,11 @@ namespace fftk {
 // NODEFER: the same kernel WITHOUT the deferral -- phase 3 runs right after phase 2 and is handed over into S1 (free
 // once row tile 1 has been read), so a team has TWO live windows instead of three (4 MiB per XCD instead of 6 against
 // the 4 MiB L2), at the price of the idle turn the deferral fills; five arrivals per transform (X5: row tile 3 landed).
+// alternating tile images with in-place first stage (see the kernel): measured +-0 at 2^16..2^20, -1 % at 2^19 and fp64
+// (profiles/r2_ab_team_variants.txt (6)), and it costs the PAIR kernel 4 VGPRs it does not have: off, kept for experiments
+#ifndef FFT_TEAM_INPLACE
+#define FFT_TEAM_INPLACE 0
+#endif
 template <typename T, int E, int GEO, bool PAIR = false, bool NODEFER = false>
 FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E) team_defer_kernel(TeamParams<T> p) {
     constexpr int NT = 4;
@@ -61,10 +66,22 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
     const unsigned tile_bytes = (unsigned)SZ << (log2L1 + log2CA);
     const unsigned phase_bytes = tile_bytes << log2TS;
 
-    unsigned char* const land = smem;
-    unsigned char* const work = smem + tile_bytes;
+    // Two tile images.  FFT_TEAM_INPLACE: they ALTERNATE -- the tile being transformed sits in image `par` and runs every
+    // stage exchange in place there (the first stage too), the next tile lands in the other one; its DMA can therefore go
+    // out when the current tile STARTS (the image was last read by the tile before it), not only once the current tile's
+    // first stage has read a shared landing image: a column tile's HBM reads are in flight for a whole tile period.
+    // Otherwise: image 0 is the landing image, image 1 the exchange ("work") image of every tile.
+    constexpr bool INPL = FFT_TEAM_INPLACE != 0;
+    unsigned char* const buf0 = smem;
+    unsigned char* const buf1 = smem + tile_bytes;
     unsigned char* const tab_bytes = smem + 2 * tile_bytes;
-    const unsigned land_lds = FFT_LDS_ADDR(land);
+    const unsigned buf0_lds = FFT_LDS_ADDR(buf0);
+    int par = 0;
+    auto stage_src = [&]() __attribute__((always_inline)) -> unsigned char* { return INPL ? (par ? buf1 : buf0) : buf0; };
+    auto stage_work = [&]() __attribute__((always_inline)) -> unsigned char* { return INPL ? (par ? buf1 : buf0) : buf1; };
+    auto dma_img = [&]() __attribute__((always_inline)) -> unsigned char* { return INPL ? (par ? buf0 : buf1) : buf0; };
+    auto dma_lds = [&]() __attribute__((always_inline)) -> unsigned { return INPL ? (par ? buf0_lds : buf0_lds + tile_bytes) : buf0_lds; };
+    auto tile_done = [&]() __attribute__((always_inline)) { if (INPL) par ^= 1; };
     {
         const vec16<T>* src = reinterpret_cast<const vec16<T>*>(p.tables);
         vec16<T>* dst = reinterpret_cast<vec16<T>*>(tab_bytes);
@@ -147,11 +164,11 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
         if (p.nt_mask & 1) {  // one branch per call, not one per chunk
             FFT_UNROLL
             for (int i = 0; i < NCH; i++)
-                if (i >= i0 && i < i1) FFT_DMA16_NT(src + i * step, land, land_lds, (unsigned)(i * nthreads + tid) * 16u);
+                if (i >= i0 && i < i1) FFT_DMA16_NT(src + i * step, dma_img(), dma_lds(), (unsigned)(i * nthreads + tid) * 16u);
         } else {
             FFT_UNROLL
             for (int i = 0; i < NCH; i++)
-                if (i >= i0 && i < i1) FFT_DMA16(src + i * step, land, land_lds, (unsigned)(i * nthreads + tid) * 16u);
+                if (i >= i0 && i < i1) FFT_DMA16(src + i * step, dma_img(), dma_lds(), (unsigned)(i * nthreads + tid) * 16u);
         }
     };
     auto dma_row_tile = [&](const unsigned char* sb, int i0, int i1) __attribute__((always_inline)) {
@@ -161,11 +178,11 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
         if (p.nt_mask & 4) {
             FFT_UNROLL
             for (int i = 0; i < NCH; i++)
-                if (i >= i0 && i < i1) FFT_DMA16_L2_NT(src + (size_t)i * nthreads * 16, land, land_lds, (unsigned)(i * nthreads + tid) * 16u);
+                if (i >= i0 && i < i1) FFT_DMA16_L2_NT(src + (size_t)i * nthreads * 16, dma_img(), dma_lds(), (unsigned)(i * nthreads + tid) * 16u);
         } else {
             FFT_UNROLL
             for (int i = 0; i < NCH; i++)
-                if (i >= i0 && i < i1) FFT_DMA16_L2(src + (size_t)i * nthreads * 16, land, land_lds, (unsigned)(i * nthreads + tid) * 16u);
+                if (i >= i0 && i < i1) FFT_DMA16_L2(src + (size_t)i * nthreads * 16, dma_img(), dma_lds(), (unsigned)(i * nthreads + tid) * 16u);
         }
     };
     // chunks of a landing DMA issued from slot s of a tile with `total` slots: two halves from slots 0 and 1
@@ -202,7 +219,7 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
         FFT_OPAQUE(tid);
         const int jB = tid & ((1 << log2CB) - 1), rB = tid >> log2CB;
         cpx<T> x[1][E][1];
-        team_all_stages<T, E, TREE>(x, land, work, twB, rB, jB, log2CB, log2TPCB, log2L2, traffic, false);
+        team_all_stages<T, E, TREE>(x, stage_src(), stage_work(), twB, rB, jB, log2CB, log2TPCB, log2L2, traffic, false);
         const long long k1 = team_tile_row0<PAIR>(ph, c, log2CB, log2TS);
         if (p.inverse) {
             FFT_UNROLL
@@ -271,9 +288,12 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
             }
         }
         ev();
+        tile_done();
     };
 
+    if (INPL) par = 1;  // the first tile lands in image 0 and is transformed there
     dma_column_tile(in_of(0), 0, 0, NCH);
+    if (INPL) par = 0;
     for (int it = 0; it < M; it++) {
         const cpx<T>* inb = in_of(it);
         cpx<T>* outb = out_of(it);
@@ -290,10 +310,12 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
             cpx<T> x[1][E][1];
             FFT_WAIT_VM0();
             FFT_SYNC_LDS();
-            team_all_stages<T, E, TREE>(x, land, work, twA, rA, jA, log2CA, log2TPCA, log2L1, [&](int s, int total) {
+            if (INPL && t + 1 < NT) dma_column_tile(inb, t + 1, 0, FFT_TEAM_DMA_FIRST(NCH));  // the other image is free since this barrier
+            team_all_stages<T, E, TREE>(x, stage_src(), stage_work(), twA, rA, jA, log2CA, log2TPCA, log2L1, [&](int s, int total) {
                 if (s > 1) return;
                 if (t + 1 < NT) {
-                    dma_column_tile(inb, t + 1, slot_i0(s), slot_i1(s, total));
+                    if (!INPL) dma_column_tile(inb, t + 1, slot_i0(s), slot_i1(s, total));
+                    else if (s == 0) dma_column_tile(inb, t + 1, FFT_TEAM_DMA_FIRST(NCH), NCH);
                 } else if (it > 0 && !NODEFER) {
                     if (s == 0) wait_all(G);  // X4 of it-1: everybody's hand-over of its phase 3 is in L2
                     dma_row_tile(S2, slot_i0(s), slot_i1(s, total));
@@ -327,6 +349,7 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
                 }
             }
             ev();
+            tile_done();
         }
         FFT_WAIT_VM0();
         FFT_SYNC_LDS();
@@ -342,7 +365,9 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
             FFT_WAIT_VM_LE(NRS_ODD);  // everything but the deferred phase's result stores: row tile 0 has landed
         } else {
             wait_all(G + 1);
+            if (INPL) par ^= 1;  // between two tiles: `par` already names the UPCOMING tile's image -- land there
             dma_row_tile(S0, 0, NCH);
+            if (INPL) par ^= 1;
             FFT_WAIT_VM0();
         }
         FFT_SYNC_LDS();
