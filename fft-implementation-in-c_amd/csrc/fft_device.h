@@ -87,6 +87,7 @@ void test_delay();  // test hook: one chosen workgroup sleeps before it register
 #define FFT_DMA16_NT(gsrc, lds_base_ptr, lds_base_addr, off) memcpy((lds_base_ptr) + (off), (gsrc), 16)
 #define FFT_DMA16_L2_NT(gsrc, lds_base_ptr, lds_base_addr, off) memcpy((lds_base_ptr) + (off), (gsrc), 16)
 #define FFT_STORE16_NT(ptr, v) (*(ptr) = (v))
+#define FFT_STORE16_SC1(ptr, v) (*(ptr) = (v))
 #define FFT_WAIT_VM_LE(n) __atomic_thread_fence(__ATOMIC_SEQ_CST)
 #else
 #include <hip/hip_runtime.h>
@@ -205,6 +206,15 @@ __device__ __forceinline__ void fft_store16_nt(V16* ptr, const V16& v) {
     __builtin_memcpy(&raw, &v, 16);
     // hand-written: __builtin_nontemporal_store of a 16-byte vector comes out as a plain global_store_dwordx4 here
     asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(ptr), "v"(raw) : "memory");
+}
+// 16-byte store written through and NOT kept in the L2 (sc1: MI355X_MICROARCH.md, "stores of each flavour")
+#define FFT_STORE16_SC1(ptr, v) fft_store16_sc1((ptr), (v))
+template <class V16>
+__device__ __forceinline__ void fft_store16_sc1(V16* ptr, const V16& v) {
+    static_assert(sizeof(V16) == 16, "one 16-byte lane access");
+    fft_u32x4 raw;
+    __builtin_memcpy(&raw, &v, 16);
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(ptr), "v"(raw) : "memory");
 }
 #define FFT_WAIT_VM_LE(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")  // at most n of my memory operations still in flight
 template <int SC1>

@@ -257,7 +257,10 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
                     }
                     vec16<T>* const d0 = reinterpret_cast<vec16<T>*>(line0 + (long long)(2 * q) * lstep);
                     vec16<T>* const d1 = reinterpret_cast<vec16<T>*>(line0 + (long long)(2 * q + 1) * lstep);
-                    if (p.nt_mask & 2) {
+                    if (FFT_ABLATE(p.nt_mask & 8)) {  // experiment: write-through stores that leave nothing in the L2
+                        FFT_STORE16_SC1(d0, first);
+                        FFT_STORE16_SC1(d1, second);
+                    } else if (p.nt_mask & 2) {
                         FFT_STORE16_NT(d0, first);
                         FFT_STORE16_NT(d1, second);
                     } else {

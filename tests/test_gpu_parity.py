@@ -269,6 +269,9 @@ def test_full_size_analytic_two_tone_config2(gpu_lib):
         buf.upload(x)
         plan.execute(buf, buf)
         y = buf.download((step, n), np.complex64)
+        for i in (0, step - 1) if b0 in (0, 512, 2048, 3584, batch - step) else ():  # the oracle at the shard boundaries of an 8-way split
+            ref = O.oracle_fft(x[i].astype(np.complex128), -1, "dit")
+            assert rel(y[i], ref) <= 1e-4 and rel(y[i], ref) <= 2e-6, (b0, i)
         for i in range(0, step, 37):
             f, g = O.two_tone_bins(n, b0 + i)
             yy = y[i].astype(np.complex128)
@@ -292,9 +295,10 @@ def test_roundtrip_full_size_config3(gpu_lib):
     buf.upload(x)
     fwd.execute(buf, buf)
     y = buf.download((batch, n), np.complex64)
-    for b in (0, batch - 1):
+    # the oracle on nine transforms: first, last, and both sides of the boundaries of an 8-way batch shard
+    for b in (0, 1, 63, 64, 255, 256, 447, 448, batch - 1):
         ref = O.oracle_fft(x[b].astype(np.complex128), -1, "dit")
-        assert rel(y[b], ref) <= 1e-4
+        assert rel(y[b], ref) <= 1e-4 and rel(y[b], ref) <= 2e-6
         f, g = O.two_tone_bins(n, b)
         assert abs(y[b][f] - n) / n < 1e-4 and abs(y[b][g] - n / 2) / n < 1e-4
     inv.execute(buf, buf)
@@ -450,6 +454,9 @@ def test_full_size_config4_shard_and_config5(gpu_lib):
             assert np.max(np.abs(y[idx, fg[:, 1]] - n / 2)) / n < 1e-4
             tot = np.linalg.norm(y.astype(np.complex128), axis=1)
             assert np.max(np.abs(tot / (n * np.sqrt(1.25)) - 1)) < 1e-5  # all energy sits in the two bins
+            for i in (0, 255):  # and the oracle on the first / last transform of every quarter of the two shards (16 transforms)
+                ref = O.oracle_fft(x[i].astype(np.complex128), -1, "dit")
+                assert rel(y[i], ref) <= 1e-4 and rel(y[i], ref) <= 2e-6, (rank, b0, i)
     plan.destroy()
     buf.free()
     n, batch = 1000003, 64
@@ -461,6 +468,10 @@ def test_full_size_config4_shard_and_config5(gpu_lib):
     fwd.execute(d, d)
     y = d.download(x.shape, x.dtype)
     assert rel(y[0], np.fft.fft(x[0])) <= 1e-6 and rel(y[-1], np.fft.fft(x[-1])) <= 1e-6
+    # the oracle (the reference's own chirp-z, restated) on nine transforms: first, last, 8-way shard boundaries
+    for b in (0, 7, 8, 15, 16, 31, 32, 56, batch - 1):
+        ref = O.oracle_fft(x[b], -1, "bluestein")
+        assert rel(y[b], ref) <= 1e-6 and rel(y[b], ref) <= 2e-9, b
     inv.execute(d, d)
     assert rel(d.download(x.shape, x.dtype), x) <= 1e-6
     fwd.destroy(); inv.destroy(); d.free()
@@ -499,7 +510,8 @@ def test_team_kernel_vs_oracle(gpu_lib, monkeypatch, log2n, dtype):
         plan.execute_ptr(buf.ptr, out.ptr)
         assert plan.team_status() == 0, "the team kernel must have done the work (teams formed, no timeout)"
         y = out.download(x.shape, dtype)
-        for b in (0, n_teams - 1, n_teams, batch - 1):
+        # the oracle on the whole first round of teams (one transform per team), the team boundaries and the ragged tail
+        for b in sorted(set(list(range(0, n_teams, max(1, n_teams // 8))) + [n_teams - 1, n_teams, 2 * n_teams - 1, 2 * n_teams, batch - 1])):
             ref = O.oracle_fft(x[b:b + 1].astype(np.complex128), d, "dit")
             r = rel(y[b:b + 1], ref)
             assert r <= TOL[np.dtype(dtype)] and r <= TIGHT[np.dtype(dtype)], (log2n, d, b, r)
@@ -523,13 +535,14 @@ def test_team_kernel_vs_oracle(gpu_lib, monkeypatch, log2n, dtype):
 
 def test_team_kernel_default_policy_and_full_size(gpu_lib, monkeypatch):
     """BASELINE configs[2] as bench.py runs it: N = 2^20 fp32 x 512 takes the team kernel by default; every one of
-    the 512 spectra is checked against the analytic two-tone answer; a batch of 64 keeps the two-pass schedule."""
+    the 512 spectra is checked against the analytic two-tone answer; a batch of 16 (below the measured crossover of 32
+    transforms, profiles/r2_batch_crossover.txt) keeps the two-pass schedule."""
     import fftlib
     fftlib.set_policy(team=1, min_batch=0)
     n, batch = 1 << 20, 512
-    small = fftlib.Plan(n, 64, -1, np.complex64)
+    small = fftlib.Plan(n, 16, -1, np.complex64)
     assert small.info().team_tiles == 4  # planned ...
-    xs = lcg(n, 64, np.complex64, seed=5)
+    xs = lcg(n, 16, np.complex64, seed=5)
     bs = fftlib.DeviceBuffer(xs.nbytes)
     bs.upload(xs)
     small.execute_ptr(bs.ptr, bs.ptr)
