@@ -140,6 +140,7 @@ struct TeamDesc {
     int n_xcc = 0, log2seats = 0, n_teams = 0;  // XCDs x seats per XCD; n_teams = n_xcc << (log2seats - log2TS)
     bool defer = false;   // team_defer_kernel: the last row phase of a transform runs after the next one's column step
     bool asplit = false;  // column step on half-height, double-width tiles (128-byte row segments), fft_team.h ASPLIT
+    bool alll2 = false;   // team_defer_kernel ALLL2 (with NODEFER): every phase handed over during the column step, two arrivals
     bool nodefer = false; // team_defer_kernel NODEFER (with PAIR): no deferred phase, two live windows per team
     bool pair = false;    // team_defer_kernel PAIR: adjacent row tiles in phases (0,1) / (2,3), 2 CB-row result segments (fp32)
     int E = 0;  // elements per thread = stage radix (fp32: 16 -> 512 threads, 8 -> 1024 threads; fp64: 8)
@@ -268,7 +269,8 @@ class Pow2Plan {
         d.defer = d.NT == 4 && !d.asplit && rt->team_defer(SZ, log2n);
         d.pair = d.defer && V == 2 && d.log2CB >= 1 && rt->team_pair(SZ, log2n);
         d.nodefer = d.pair && rt->team_nodefer(SZ, log2n);
-        d.scratch_bytes = ((size_t)SZ << (log2TE + d.log2TS)) * (d.defer ? 3 : 2) * (size_t)d.n_teams;  // 2 (3) windows of TS tiles per team
+        d.alll2 = d.nodefer && rt->team_alll2(SZ, log2n);
+        d.scratch_bytes = ((size_t)SZ << (log2TE + d.log2TS)) * (d.defer ? 4 : 2) * (size_t)d.n_teams;  // 2 (deferred kernel: up to 4) windows of TS tiles per team
         d.tables = (cpx<T>*)rt->dmalloc(blob.size() * SZ);
         d.scratch = (unsigned char*)rt->dmalloc(d.scratch_bytes);
         // [ sticky words | control block ]: only the control block is zeroed per launch
@@ -302,7 +304,11 @@ class Pow2Plan {
         const long long grid = (long long)team.n_xcc << team.log2seats;
         constexpr int GEO = fftk::TeamGeo<T, LOG2N>::value;
         if (GEO == 0) return;
-        if (team.defer && team.pair && team.nodefer && fftk::TeamPairBuilt<T, LOG2N>::value)
+        if (team.defer && team.pair && team.nodefer && team.alll2 && fftk::TeamPairBuilt<T, LOG2N>::value)
+            rt->launch_coresident(fftk::team_defer_kernel<T, 8 * V, (GEO ? GEO : 1), fftk::TeamPairBuilt<T, LOG2N>::value, fftk::TeamPairBuilt<T, LOG2N>::value,
+                                                          fftk::TeamPairBuilt<T, LOG2N>::value>,
+                                  grid, team.nthreads, (size_t)team.smem_bytes, tp);
+        else if (team.defer && team.pair && team.nodefer && fftk::TeamPairBuilt<T, LOG2N>::value)
             rt->launch_coresident(fftk::team_defer_kernel<T, 8 * V, (GEO ? GEO : 1), fftk::TeamPairBuilt<T, LOG2N>::value, fftk::TeamPairBuilt<T, LOG2N>::value>,
                                   grid, team.nthreads, (size_t)team.smem_bytes, tp);
         else if (team.defer && team.pair && fftk::TeamPairBuilt<T, LOG2N>::value)
@@ -320,7 +326,9 @@ class Pow2Plan {
     template <int NT>
     void launch_team_emu(const fftk::TeamParams<T>& tp) {
         const long long grid = (long long)team.n_xcc << team.log2seats;
-        if (NT == 4 && team.defer && team.pair && team.nodefer)
+        if (NT == 4 && team.defer && team.pair && team.nodefer && team.alll2)
+            rt->launch_coresident(fftk::team_defer_kernel<T, 8 * V, 0, (V == 2), true, (V == 2)>, grid, team.nthreads, (size_t)team.smem_bytes, tp);
+        else if (NT == 4 && team.defer && team.pair && team.nodefer)
             rt->launch_coresident(fftk::team_defer_kernel<T, 8 * V, 0, (V == 2), true>, grid, team.nthreads, (size_t)team.smem_bytes, tp);
         else if (NT == 4 && team.defer && team.pair)
             rt->launch_coresident(fftk::team_defer_kernel<T, 8 * V, 0, (V == 2)>, grid, team.nthreads, (size_t)team.smem_bytes, tp);

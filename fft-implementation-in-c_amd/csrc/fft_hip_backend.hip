@@ -147,6 +147,10 @@ struct HipRT {
         static const int on = FFT_EXP_ENV("FFT_HIP_TEAM_PAIR") ? atoi(FFT_EXP_ENV("FFT_HIP_TEAM_PAIR")) : FFT_TEAM_PAIR_DEFAULT;
         return on && elem_bytes == 8 && (log2n == 19 || log2n == 20);
     }
+    bool team_alll2(int, int) {
+        static const int on = FFT_EXP_ENV("FFT_HIP_TEAM_ALLL2") ? atoi(FFT_EXP_ENV("FFT_HIP_TEAM_ALLL2")) : 0;
+        return on != 0;
+    }
     // NODEFER (two live windows per team instead of three): measured with the paired kernel (profiles/r2_pmc_variants.txt)
     // n = 2^20: window refetch 3.8 -> 1.2 GB per 512 transforms (L2 hit rate 51 -> 67 %), +1..2.5 % throughput; n = 2^19
     // (teams of 16: the turn costs more than the hits return): -1 %

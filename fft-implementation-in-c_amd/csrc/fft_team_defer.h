@@ -34,11 +34,15 @@ namespace fftk {
 #ifndef FFT_TEAM_INPLACE
 #define FFT_TEAM_INPLACE 0
 #endif
-template <typename T, int E, int GEO, bool PAIR = false, bool NODEFER = false>
+// ALLL2 (with NODEFER): EVERY phase is handed over during the column step (four windows per team, no kept registers):
+// two arrivals per transform -- X1 "my column step's hand-over is in L2", X2 "my four row tiles have landed" -- instead of
+// five, at the price of a window footprint of the whole intermediate (8 MiB per XCD at n = 2^20: Infinity Cache, not L2).
+template <typename T, int E, int GEO, bool PAIR = false, bool NODEFER = false, bool ALLL2 = false>
 FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E) team_defer_kernel(TeamParams<T> p) {
     constexpr int NT = 4;
     constexpr bool TREE = TeamTwTree<T, GEO>::value;
     static_assert(!PAIR || vec16<T>::V == 2, "paired result stores: fp32 only");
+    static_assert(!ALLL2 || (NODEFER && PAIR), "ALLL2 is a variant of the paired NODEFER schedule");
     constexpr int V16 = vec16<T>::V;
     constexpr int log2V16 = Log2<V16>::value;
     constexpr int log2E = Log2<E>::value;
@@ -111,7 +115,7 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
     const int M = team < p.nb ? (p.nb - team + n_teams - 1) / n_teams : 0;  // transforms of this team
     if (M == 0) return;
 
-    unsigned char* const sbase = p.scratch + (size_t)team * 3 * phase_bytes;  // windows S0, S1, S2
+    unsigned char* const sbase = p.scratch + (size_t)team * 4 * phase_bytes;  // windows S0, S1, S2 (ALLL2: and S3)
     unsigned* const flags = p.ctl + TEAM_CTL_FLAGS + 32 * team;
 
     int n_ev = 0;
@@ -151,6 +155,7 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
     unsigned char* const S0 = sbase;
     unsigned char* const S1 = sbase + phase_bytes;
     unsigned char* const S2 = sbase + 2 * (size_t)phase_bytes;
+    unsigned char* const S3 = sbase + 3 * (size_t)phase_bytes;
 
     cpx<T> keep[NT][NK * EP];  // the hand-over of phases 2, 3
 
@@ -161,6 +166,7 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
         const int c0 = column_block(t) << log2CA;
         const cpx<T>* src = inb + ((long long)(tid >> log2CPR) << log2L2) + c0 + V16 * (tid & ((1 << log2CPR) - 1));
         const long long step = (long long)(nthreads >> log2CPR) << log2L2;
+        if (FFT_ABLATE(p.ablate & 8)) return;  // profiling (-DFFT_EXPERIMENTS only): no input stream
         if (p.nt_mask & 1) {  // one branch per call, not one per chunk
             FFT_UNROLL
             for (int i = 0; i < NCH; i++)
@@ -219,7 +225,16 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
         FFT_OPAQUE(tid);
         const int jB = tid & ((1 << log2CB) - 1), rB = tid >> log2CB;
         cpx<T> x[1][E][1];
-        team_all_stages<T, E, TREE>(x, stage_src(), stage_work(), twB, rB, jB, log2CB, log2TPCB, log2L2, traffic, false);
+        if (!FFT_ABLATE(p.ablate & 2)) {
+            team_all_stages<T, E, TREE>(x, stage_src(), stage_work(), twB, rB, jB, log2CB, log2TPCB, log2L2, traffic, false);
+        } else {  // profiling: the memory side alone -- the hooks' traffic without the stages between them
+            FFT_UNROLL
+            for (int e = 0; e < E; e++) x[0][e][0] = mk<T>((T)(tid + e), (T)ph);
+            FFT_SYNC_LDS();
+            traffic(0, 3);
+            traffic(1, 3);
+            traffic(2, 3);
+        }
         const long long k1 = team_tile_row0<PAIR>(ph, c, log2CB, log2TS);
         if (p.inverse) {
             FFT_UNROLL
@@ -257,7 +272,8 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
                     }
                     vec16<T>* const d0 = reinterpret_cast<vec16<T>*>(line0 + (long long)(2 * q) * lstep);
                     vec16<T>* const d1 = reinterpret_cast<vec16<T>*>(line0 + (long long)(2 * q + 1) * lstep);
-                    if (FFT_ABLATE(p.nt_mask & 8)) {  // experiment: write-through stores that leave nothing in the L2
+                    if (FFT_ABLATE(p.ablate & 4)) {  // profiling: no result stream
+                    } else if (FFT_ABLATE(p.nt_mask & 8)) {  // experiment: write-through stores that leave nothing in the L2
                         FFT_STORE16_SC1(d0, first);
                         FFT_STORE16_SC1(d1, second);
                     } else if (p.nt_mask & 2) {
@@ -300,7 +316,7 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
     for (int it = 0; it < M; it++) {
         const cpx<T>* inb = in_of(it);
         cpx<T>* outb = out_of(it);
-        const int G = (NODEFER ? 5 : 4) * it;  // this transform's arrivals are G + 1 .. G + 4 (NODEFER: .. G + 5)
+        const int G = (ALLL2 ? 2 : NODEFER ? 5 : 4) * it;  // this transform's arrivals are G + 1 .. G + 4 (NODEFER: .. G + 5; ALLL2: G + 1, G + 2)
         int tid = tid_invariant;
         FFT_OPAQUE(tid);
         const int jA = tid & ((1 << log2CA) - 1), rA = tid >> log2CA;
@@ -314,7 +330,7 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
             FFT_WAIT_VM0();
             FFT_SYNC_LDS();
             if (INPL && t + 1 < NT) dma_column_tile(inb, t + 1, 0, FFT_TEAM_DMA_FIRST(NCH));  // the other image is free since this barrier
-            team_all_stages<T, E, TREE>(x, stage_src(), stage_work(), twA, rA, jA, log2CA, log2TPCA, log2L1, [&](int s, int total) {
+            auto column_traffic = [&](int s, int total) __attribute__((always_inline)) {
                 if (s > 1) return;
                 if (t + 1 < NT) {
                     if (!INPL) dma_column_tile(inb, t + 1, slot_i0(s), slot_i1(s, total));
@@ -323,13 +339,26 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
                     if (s == 0) wait_all(G);  // X4 of it-1: everybody's hand-over of its phase 3 is in L2
                     dma_row_tile(S2, slot_i0(s), slot_i1(s, total));
                 }
-            }, p.inverse != 0);
-            {
+            };
+            if (!FFT_ABLATE(p.ablate & 2)) {
+                team_all_stages<T, E, TREE>(x, stage_src(), stage_work(), twA, rA, jA, log2CA, log2TPCA, log2L1, column_traffic, p.inverse != 0);
                 const unsigned n2 = (unsigned)(column_block(t) << log2CA) + (unsigned)jA;
                 team_interpass_twiddle<T, E, TREE>(x, tab + p.o_t0, tab + p.o_t1, p.t0_bits, (unsigned)rA * n2, n2 << log2TPCA);
+            } else {  // profiling: the memory side alone
+                FFT_UNROLL
+                for (int e = 0; e < E; e++) x[0][e][0] = mk<T>((T)(tid + e), (T)t);
+                FFT_SYNC_LDS();
+                column_traffic(0, 3);
+                column_traffic(1, 3);
             }
             if (t == 0 && it > 0) wait_all(G);  // S0 / S1 were last read by row tiles 2 / 1 of it-1 (X4 covers both)
-            if constexpr (PAIR) {
+            if constexpr (ALLL2) {
+                cpx<T> y[E];
+                FFT_UNROLL
+                for (int ee = 0; ee < E; ee++) y[ee] = x[0][ee][0];
+                team_hand_over_rows<T, E, true>([&](int phase) -> unsigned char* { return sbase + (size_t)phase * phase_bytes; }, y, 0,
+                                                (column_block(t) << log2CA) + jA, rA, log2TPCA, log2CB, log2TS, tile_bytes, 1 << log2CA);
+            } else if constexpr (PAIR) {
                 cpx<T> y[2 * EP];
                 FFT_UNROLL
                 for (int ee = 0; ee < 2 * EP; ee++) y[ee] = x[0][ee][0];
@@ -344,11 +373,13 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
                     team_hand_over<T, EP>(ph ? S1 : S0, y, (column_block(t) << log2CA) + jA, rA, log2TPCA, log2CB, tile_bytes, 1 << log2CA);
                 }
             }
-            FFT_UNROLL
-            for (int tt = 0; tt < NT; tt++) {
-                if (t == tt) {
-                    FFT_UNROLL
-                    for (int k = 0; k < NK * EP; k++) keep[tt][k] = x[0][2 * EP + k][0];
+            if constexpr (!ALLL2) {
+                FFT_UNROLL
+                for (int tt = 0; tt < NT; tt++) {
+                    if (t == tt) {
+                        FFT_UNROLL
+                        for (int k = 0; k < NK * EP; k++) keep[tt][k] = x[0][2 * EP + k][0];
+                    }
                 }
             }
             ev();
@@ -357,6 +388,37 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
         FFT_WAIT_VM0();
         FFT_SYNC_LDS();
         arrive(G + 1);  // X1
+
+        if constexpr (ALLL2) {
+            // every phase is in its own window since X1: four row phases without a single wait between them
+            wait_all(G + 1);
+            if (INPL) par ^= 1;
+            dma_row_tile(S0, 0, NCH);
+            if (INPL) par ^= 1;
+            FFT_WAIT_VM0();
+            FFT_SYNC_LDS();
+            row_body(outb, 0, [&](int s, int total) {
+                if (s <= 1) dma_row_tile(S1, slot_i0(s), slot_i1(s, total));
+            });
+            FFT_WAIT_VM_LE(NRS_EVEN);
+            FFT_SYNC_LDS();
+            row_body(outb, 1, [&](int s, int total) {
+                if (s <= 1) dma_row_tile(S2, slot_i0(s), slot_i1(s, total));
+            });
+            FFT_WAIT_VM_LE(NRS_ODD);
+            FFT_SYNC_LDS();
+            row_body(outb, 2, [&](int s, int total) {
+                if (s <= 1) dma_row_tile(S3, slot_i0(s), slot_i1(s, total));
+            });
+            FFT_WAIT_VM_LE(NRS_EVEN);  // row tile 3 has landed
+            FFT_SYNC_LDS();
+            arrive(G + 2);  // X2: my four row tiles have landed -- the windows may be rewritten once everybody is here
+            row_body(outb, 3, [&](int s, int total) {
+                if (s > 1) return;
+                if (it + 1 < M) dma_column_tile(in_of(it + 1), 0, slot_i0(s), slot_i1(s, total));
+            });
+            continue;
+        }
 
         // ================= the turn: the deferred phase 3 of it-1 runs while X1 spreads and row tile 0 makes its trip
         if (it > 0 && !NODEFER) {

@@ -180,7 +180,7 @@ def test_team_kernel(n, batch, dtype, log2seats, n_xcc, threads, lds, tiles, pla
     (1 << 16, 3, 3, 2, 128, 1 << 17, 6),  # 64 x 1024: the production stage sequence 16 x 16 x 4 with the bank swizzle
     (1 << 14, 6, 2, 2, 64, 65536, 8),     # 256 x 64: TPCA = 16 > CB = 4 ... every kind of slot <-> phase relation
 ])
-@pytest.mark.parametrize("nodefer", [False, True])
+@pytest.mark.parametrize("nodefer", [False, True, "alll2"])
 def test_team_kernel_paired_row_tiles(n, batch, log2seats, n_xcc, threads, lds, l1, nodefer, monkeypatch):
     """team_defer_kernel PAIR: a seat's row tiles of phases (0, 1) and (2, 3) are adjacent blocks of rows, the even phase's
     results wait in registers (phase 2's across the next transform's column step) and both are written as double-width
@@ -188,6 +188,8 @@ def test_team_kernel_paired_row_tiles(n, batch, log2seats, n_xcc, threads, lds, 
     monkeypatch.setenv("FFT_EMU_TEAM_PAIR", "1")
     if nodefer:  # NODEFER: phase 3 right after phase 2, handed over into S1: two live windows, five arrivals
         monkeypatch.setenv("FFT_EMU_TEAM_NODEFER", "1")
+    if nodefer == "alll2":  # ALLL2: every phase handed over during the column step, four windows, two arrivals
+        monkeypatch.setenv("FFT_EMU_TEAM_ALLL2", "1")
     if l1:
         monkeypatch.setenv("FFT_HIP_TEAM_L1", str(l1))
     x = O.gen_lcg(n, 17, batch).astype(np.complex64)
