@@ -1,6 +1,8 @@
 #!/bin/bash
 # L2-residency probe: membench5 timings, then its HBM-side traffic per dispatch (separate --pmc passes), then the
 # team kernel's traffic with and without the non-temporal bits on its HBM streams.  Writes under gpurun_out/.
+# the switches below exist only in the -DFFT_EXPERIMENTS build of the library
+export FFT_LIB_PATH=${FFT_LIB_PATH:-${GRAFT_REPO_ROOT:-/root/repo}/fft-implementation-in-c_amd/libfft_mi355x_exp.so}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/l2probe
 mkdir -p $O

@@ -2,6 +2,8 @@
 # What evicts the hand-over window from L2?  HBM-side traffic of team_fft_kernel (FFT_HIP_TEAM_DEFER=0) with its
 # streams switched off one by one (FFT_HIP_TEAM_ABLATE 4 = no result stores, 8 = no column-tile DMA) and with the
 # non-temporal bits (FFT_HIP_TEAM_NT).  Results are garbage under ablation: --no-check.  Output: gpurun_out/ablate/.
+# the switches below exist only in the -DFFT_EXPERIMENTS build of the library
+export FFT_LIB_PATH=${FFT_LIB_PATH:-${GRAFT_REPO_ROOT:-/root/repo}/fft-implementation-in-c_amd/libfft_mi355x_exp.so}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/ablate
 rm -rf $O; mkdir -p $O

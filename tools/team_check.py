@@ -9,6 +9,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "fft-implementation-in-c_amd"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+os.environ.setdefault("FFT_LIB_PATH", os.path.join(ROOT, "fft-implementation-in-c_amd", "libfft_mi355x_exp.so"))  # experiment switches live in the -DFFT_EXPERIMENTS build only
 import fftlib  # noqa: E402
 import oracle_lib as O  # noqa: E402
 
