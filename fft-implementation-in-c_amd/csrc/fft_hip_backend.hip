@@ -765,6 +765,54 @@ int fft_gpu_host_is_registered_hip(const void* host_ptr) {
     }
     return attr.type == hipMemoryTypeHost ? 1 : 0;
 }
+// Device copy benchmark on the current device: the best of a few launch shapes of copy16_kernel over `bytes` bytes
+// (read + written bytes per second, GB/s); what bench.py quotes as the box's practical ceiling.  -1 on failure.
+double fft_gpu_copy_bench_hip(size_t bytes, int iters) {
+    if (!g_initialized || bytes < (1u << 20) || iters <= 0) return -1.0;
+    void *a = nullptr, *b = nullptr;
+    if (hipMalloc(&a, bytes) != hipSuccess || hipMalloc(&b, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        if (a) (void)hipFree(a);
+        return -1.0;
+    }
+    (void)hipMemset(a, 1, bytes);
+    (void)hipMemset(b, 0, bytes);
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    const long long n16 = (long long)(bytes / 16);
+    const DeviceInfo* di = device_info(g_device);
+    const int cus = di ? di->cus : 256;
+    double best = -1.0;
+    for (int shape = 0; shape < 6; shape++) {
+        const int per_cu = shape < 3 ? 8 : 16;  // resident 256-thread workgroups per CU
+        const unsigned grid = (unsigned)(cus * per_cu);
+        for (int rep = 0; rep < 2; rep++) {
+            (void)hipEventRecord(e0, nullptr);
+            for (int it = 0; it < iters; it++) {
+                switch (shape % 3) {
+                    case 0: hipLaunchKernelGGL(fftk::copy16_kernel<1>, dim3(grid), dim3(256), 0, nullptr, (const fftk::vec16<float>*)a, (fftk::vec16<float>*)b, n16); break;
+                    case 1: hipLaunchKernelGGL(fftk::copy16_kernel<4>, dim3(grid), dim3(256), 0, nullptr, (const fftk::vec16<float>*)a, (fftk::vec16<float>*)b, n16); break;
+                    default: hipLaunchKernelGGL(fftk::copy16_kernel<8>, dim3(grid), dim3(256), 0, nullptr, (const fftk::vec16<float>*)a, (fftk::vec16<float>*)b, n16); break;
+                }
+            }
+            (void)hipEventRecord(e1, nullptr);
+            if (hipEventSynchronize(e1) != hipSuccess) break;
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            if (rep == 1 && ms > 0.f) {
+                const double gbs = 2.0 * (double)bytes * iters / (ms * 1e-3) / 1e9;
+                if (gbs > best) best = gbs;
+            }
+        }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(a);
+    (void)hipFree(b);
+    (void)hipGetLastError();
+    return best;
+}
 void fft_gpu_debug_counters_hip(long long* device_allocations, long long* streams_created) {
     if (device_allocations) *device_allocations = __atomic_load_n(&g_count_allocs, __ATOMIC_RELAXED);
     if (streams_created) *streams_created = __atomic_load_n(&g_count_streams, __ATOMIC_RELAXED);

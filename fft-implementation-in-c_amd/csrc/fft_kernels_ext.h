@@ -128,4 +128,20 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS(256) psd_onesided_kernel(const cpx<T>* X, T* p
     }
 }
 
+// Plain device copy, 16 bytes per lane, `unroll` independent accesses in flight per thread, grid-stride: the practical HBM
+// ceiling of the box the benchmark runs on (MI355X_MICROARCH.md quotes 6.29 TB/s for a float4 copy).
+template <int UNROLL>
+FFT_KERNEL void FFT_LAUNCH_BOUNDS(256) copy16_kernel(const vec16<float>* in, vec16<float>* out, long long n16) {
+    const long long stride = FFT_NBLOCKS * FFT_NTHREADS;
+    long long i = FFT_BID * FFT_NTHREADS + FFT_TID;
+    for (; i + (UNROLL - 1) * stride < n16; i += UNROLL * stride) {
+        vec16<float> v[UNROLL];
+        FFT_UNROLL
+        for (int u = 0; u < UNROLL; u++) v[u] = in[i + u * stride];
+        FFT_UNROLL
+        for (int u = 0; u < UNROLL; u++) out[i + u * stride] = v[u];
+    }
+    for (; i < n16; i += stride) out[i] = in[i];
+}
+
 }  // namespace fftk

@@ -119,6 +119,9 @@ size_t fft_gpu_memory_bytes_hip(fft_gpu_memory_t mem);
 int fft_gpu_host_register_hip(void* host_ptr, size_t bytes);
 int fft_gpu_host_unregister_hip(void* host_ptr);
 int fft_gpu_host_is_registered_hip(const void* host_ptr); /* 1 page-locked and known to the runtime, 0 not */
+/* the box's practical memory ceiling: best read + write rate (GB/s) of a plain 16-byte-per-lane device copy over `bytes`
+ * bytes, a few launch shapes, `iters` launches each; -1 on failure */
+double fft_gpu_copy_bench_hip(size_t bytes, int iters);
 /* resource counters of this process (tests): device allocations and streams the backend has created so far */
 void fft_gpu_debug_counters_hip(long long* device_allocations, long long* streams_created);
 /* FFT_MEASURE at the device level: time the plan's candidate schedules (team kernel vs multi-pass) on scratch buffers of
