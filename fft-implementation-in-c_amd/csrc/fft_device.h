@@ -68,9 +68,11 @@ inline unsigned cas_u32(unsigned* p, unsigned expected, unsigned desired) {  // 
     return expected;
 }
 void test_delay();  // test hook: one chosen workgroup sleeps before it registers (FFT_EMU_LATE_BLOCK / _MS)
+bool test_drop();   // test hook: this workgroup leaves right after the team has formed (FFT_EMU_DROP_BLOCK): a hung member
 }  // namespace emu
 #define FFT_ATOMIC_CAS_AGENT(p, expected, desired) emu::cas_u32((p), (expected), (desired))
 #define FFT_TEST_DELAY() emu::test_delay()
+#define FFT_TEST_DROP() emu::test_drop()
 #define FFT_L2_FLAG_STORE(p, v) __atomic_store_n((p), (v), __ATOMIC_SEQ_CST)
 #define FFT_L2_FLAG_LOAD(p) __atomic_load_n((p), __ATOMIC_SEQ_CST)
 #define FFT_L2_COUNT_ADD(p) ((void)__atomic_fetch_add((p), 1u, __ATOMIC_SEQ_CST))
@@ -157,6 +159,7 @@ __device__ __forceinline__ unsigned fft_cas_agent(unsigned* p, unsigned expected
 }
 #define FFT_ATOMIC_CAS_AGENT(p, expected, desired) fft_cas_agent((p), (expected), (desired))
 #define FFT_TEST_DELAY() ((void)0)
+#define FFT_TEST_DROP() false
 // Same-XCD signalling through the XCD's own L2: a PLAIN dword store stays in L2 (write-through L1), an sc1 load
 // bypasses the reader's L1 and is served by that L2.  Valid ONLY between workgroups that read the same XCC id.
 // (hand-written: a volatile C store comes out as flat_store_dword sc0 sc1, i.e. written through to memory)

@@ -171,6 +171,12 @@ FFT_DEVICE void team_report_timeout(const TeamParams<T>& p) {
 #ifndef FFT_TEAM_TW_TREE
 #define FFT_TEAM_TW_TREE 1
 #endif
+#ifndef FFT_TEAM_TW_TREE_F64      // fp64 too (4.2e-16 -> 6.9e-16 relative: far inside the 1e-6 budget): 2^19 +2.5 %, 2^18 +4.5 %, 2^17 +2 %, below +-0
+#define FFT_TEAM_TW_TREE_F64 1
+#endif
+#ifndef FFT_TEAM_TW_TREE_F64_MIN  // smallest log2 n
+#define FFT_TEAM_TW_TREE_F64_MIN 17
+#endif
 
 #define FFT_TEAM_GEO(l1, l2, ca, cb, ts) ((l1) | ((l2) << 5) | ((ca) << 10) | ((cb) << 15) | ((ts) << 20))
 
@@ -188,12 +194,13 @@ struct StageHookAt {
     FFT_DEVICE void operator()() const { hook(s, total); }
 };
 
-// which geometries build their twiddles as powers (FFT_TEAM_TW_TREE): fp32 from n = 2^18 up (measured, profiles/r2_ab_tree.txt:
-// 2^20 +7 %, 2^19 +1.4 %, 2^18 +0.8 %, 2^16 -1.4 %); fp64 keeps its table reads (rounding budget 1e-11 in the tests);
-// GEO = 0 (the emulation's generic geometry) exercises the power path
+// which geometries build their twiddles as powers (FFT_TEAM_TW_TREE; measured, profiles/r2_ab_team_variants.txt (3), (11)): fp32
+// from n = 2^18 up (2^20 +7 %, 2^19 +1.4 %, 2^18 +0.8 %, 2^16 -1.4 %), fp64 from 2^17 up; GEO = 0 (the emulation's generic
+// geometry) exercises the power path
 template <typename T, int GEO>
 struct TeamTwTree {
-    static constexpr bool value = FFT_TEAM_TW_TREE && sizeof(T) == 4 && (GEO == 0 || ((GEO & 31) + ((GEO >> 5) & 31)) >= 18);
+    static constexpr bool value = FFT_TEAM_TW_TREE && (sizeof(T) == 4 || FFT_TEAM_TW_TREE_F64) &&
+                                  (GEO == 0 || ((GEO & 31) + ((GEO >> 5) & 31)) >= (sizeof(T) == 4 ? 18 : FFT_TEAM_TW_TREE_F64_MIN));
 };
 
 template <typename T, int E, bool TREE = (FFT_TEAM_TW_TREE && sizeof(T) == 4), class Hook>

@@ -114,6 +114,7 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(4096 * vec16<T>::V / E, 16 * vec16<T>::V / E)
     const int n_teams = p.n_xcc << (p.log2seats - log2TS);
     const int M = team < p.nb ? (p.nb - team + n_teams - 1) / n_teams : 0;  // transforms of this team
     if (M == 0) return;
+    if (FFT_TEST_DROP()) return;  // emulation only: a member that never arrives -- its team's waits must run into their bound
 
     unsigned char* const sbase = p.scratch + (size_t)team * 4 * phase_bytes;  // windows S0, S1, S2 (ALLL2: and S3)
     unsigned* const flags = p.ctl + TEAM_CTL_FLAGS + 32 * team;

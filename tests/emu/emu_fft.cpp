@@ -25,6 +25,12 @@ long long clock_ticks() {  // 100 MHz, like the device's wall clock
 
 static thread_local unsigned* g_xchg = nullptr;  // 1024 words per workgroup
 
+// test hook (FFT_TEST_DROP): workgroup FFT_EMU_DROP_BLOCK leaves right after team formation, as if it hung
+bool test_drop() {
+    const char* b = getenv("FFT_EMU_DROP_BLOCK");
+    return b && (unsigned)atoi(b) == blockIdx_.x;
+}
+
 // test hook (FFT_TEST_DELAY in team_form): workgroup FFT_EMU_LATE_BLOCK sleeps FFT_EMU_LATE_MS before it registers
 void test_delay() {
     const char* b = getenv("FFT_EMU_LATE_BLOCK");

@@ -53,7 +53,10 @@ struct Runtime {
     bool team_alll2(int, int) { return getenv("FFT_EMU_TEAM_ALLL2") != nullptr; }
     bool team_nodefer(int, int) { return getenv("FFT_EMU_TEAM_NODEFER") != nullptr; }
     bool team_pair(int elem_bytes, int) { return elem_bytes == 8 && getenv("FFT_EMU_TEAM_PAIR") != nullptr; }
-    long long team_timeout_ticks() { return 60ll * 100000000ll; }
+    long long team_timeout_ticks() {  // FFT_EMU_TEAM_TIMEOUT_MS: short, for the test with a member that never arrives
+        const char* e = getenv("FFT_EMU_TEAM_TIMEOUT_MS");
+        return e ? atoll(e) * 100000ll : 60ll * 100000000ll;
+    }
     // formation: generous by default (host threads start slowly); FFT_EMU_FORM_TIMEOUT_MS makes it short for the test
     // that delays one workgroup past it
     long long team_form_timeout_ticks() {

@@ -240,6 +240,20 @@ def test_team_kernel_late_workgroup_cannot_split_the_launch(late_block, plain, m
         assert rel(y, oracle(x, -1)) < TEAM_TOL[np.complex64]
 
 
+def test_team_kernel_hung_member_is_reported_even_after_later_launches(monkeypatch):
+    """A member of a formed team never arrives (emulation hook): its team's waits run into their bound, the status word
+    says TIMEOUT -- written by compare-and-swap, so it can never overwrite NO_TEAMS -- and the STICKY counter keeps the
+    report although the control block is zeroed by the next launch (round-1 ADVICE: a timeout of an earlier queued
+    execute used to be erased).  info[5] = 1 + status + 10 * sticky fallbacks + 100 * sticky timeouts."""
+    monkeypatch.setenv("FFT_EMU_TEAM_TIMEOUT_MS", "300")
+    monkeypatch.setenv("FFT_EMU_DROP_BLOCK", "3")
+    x = O.gen_lcg(4096, 4, 5).astype(np.complex64)
+    _, info = E.emu_fft_team(x, -1, log2seats=2, n_xcc=2, threads=16, lds_budget=16384)
+    status, timeouts = (info[5] - 1) % 10, info[5] // 100
+    assert status == 2, info[5]
+    assert 1 <= timeouts <= 3, "every surviving member of the hung team (4 seats, one dropped) reports once"
+
+
 def test_team_kernel_slow_start_inside_the_timeout_still_forms_teams(monkeypatch):
     """A workgroup that registers late but inside the formation timeout: the launch proceeds as a team."""
     monkeypatch.setenv("FFT_EMU_FORM_TIMEOUT_MS", "5000")
