@@ -406,7 +406,10 @@ def main():
     ev_ms_per_step = ev_ms / args.steps
     achieved = bytes_alg_per_step_gpu / (ev_ms_per_step * 1e-3) / 1e9
     n_groups = -(-batch // max(1, info.chunk_batch)) if info.n_passes > 1 else 1
-    launches = (3 + 2 * max(1, info.n_passes) * n_groups) if info.bluestein_m else info.n_passes * n_groups
+    if info.bluestein_m:  # two transforms of length m per group; fused: 1 no element-wise kernels, 2 and the middle two passes as one
+        launches = ((2 * max(1, info.n_passes) - (1 if info.fused == 2 else 0)) * n_groups) + (0 if info.fused else 3)
+    else:
+        launches = info.n_passes * n_groups
     units_per_launch = min(batch, info.chunk_batch) if info.n_passes > 1 else batch
     if team:
         # ONE team_fft_kernel launch carries the whole batch: every transform is read from HBM once and written once
@@ -424,6 +427,10 @@ def main():
         kernel_desc = ("tile_fft_kernel: one launch per pass per group of %d transforms (%d launches per step); the "
                        "dominant unit of work is the launch SET that carries a group through all %d passes"
                        % (units_per_launch, launches, max(1, info.n_passes)))
+        if info.bluestein_m:
+            kernel_desc += ("; Bluestein = forward + inverse transform of length %d with the chirp / spectral products fused into "
+                            "their first load and last store%s" % (info.bluestein_m, ", the forward's last pass and the inverse's first "
+                            "as ONE kernel (tile_fft_ba_kernel)" if info.fused == 2 else ""))
 
     # HBM traffic from the PMC counters comes from separate rocprofv3 --pmc runs (never combined with tracing);
     # the committed summary is attached when it was taken on this same workload / plan shape.

@@ -39,6 +39,7 @@
 #include <vector>
 
 #include "fft_kernels.h"
+#include "fft_kernels_chain.h"
 #include "fft_team_list.h"
 #include "fft_team_defer.h"
 
@@ -171,6 +172,7 @@ class Pow2Plan {
     std::vector<PassDesc> passes;
     cpx<T>* scratch = nullptr;
     size_t scratch_bytes = 0;
+    cpx<T>* scratch2 = nullptr;  // execute_chain: the inverse transform's image (allocated on first use, scratch_bytes)
     std::vector<cpx<T>*> pass_tables;  // one device blob per pass: [sa | sb | t0 | t1 | t2]
     cpx<T>* tw_half = nullptr;  // W_n^k, k < n/2 (RADIX2_GLOBAL)
     TeamDesc<T> team;           // team.ok: execute() runs the team kernel, with the two-pass plan queued behind it as fallback
@@ -189,6 +191,8 @@ class Pow2Plan {
         pass_tables.clear();
         if (tw_half) rt->dfree(tw_half);
         if (scratch) rt->dfree(scratch);
+        if (scratch2) rt->dfree(scratch2);
+        scratch2 = nullptr;
         if (team.tables) rt->dfree(team.tables);
         if (team.scratch) rt->dfree(team.scratch);
         if (team.sticky) rt->dfree(team.sticky);
@@ -522,6 +526,20 @@ class Pow2Plan {
         return 8.0;
     }
 
+    // Plans that run forward + inverse back to back (Bluestein, the fused consumers) set this before build(): a split whose
+    // first and last pass share a tile lets the middle two passes of the pair run as ONE kernel (execute_chain), which is
+    // worth more than the wider row segments of the split the cost model would pick for a single transform
+    // (tools/ab_chain.py, profiles/r2_ab_chain.txt).  The bonus is in the cost model's unit (1 = one pass).
+    bool prefer_chain = false;
+    static bool ends_chainable(const PassDesc& a, const PassDesc& b) {
+        return a.log2L == b.log2L && a.log2C == b.log2C && a.E == 8 && b.E == 8 && a.nthreads == b.nthreads && a.nthreads <= 512 &&
+               a.log2H == 0 && b.log2H == 0;
+    }
+    double chain_bonus(const PassDesc& a, const PassDesc& b) const {
+        static const double bonus = FFT_EXP_ENV("FFT_HIP_CHAIN_BONUS") ? atof(FFT_EXP_ENV("FFT_HIP_CHAIN_BONUS")) : 0.4;
+        return (prefer_chain && ends_chainable(a, b)) ? bonus : 0.0;
+    }
+
     bool build(RT* runtime, int log2n_, int algo_, int batch) {
         rt = runtime;
         log2n = log2n_;
@@ -601,7 +619,7 @@ class Pow2Plan {
                 b.in_blk_bits = a.log2C;   // n2 -> block n2 / C_A, column n2 % C_A
                 b.in_blk_stride = CA << l1;
             }
-            const double cost = seg_cost(a.seg_bytes) + 0.5 + 0.5 * store_cost(b.seg_bytes) + 0.01 * abs(l1 - l2);
+            const double cost = seg_cost(a.seg_bytes) + 0.5 + 0.5 * store_cost(b.seg_bytes) + 0.01 * abs(l1 - l2) - chain_bonus(a, b);
             if (cost < best_cost) {
                 best_cost = cost;
                 best.clear();
@@ -637,7 +655,7 @@ class Pow2Plan {
                     if (!choose_tile(b, 1ll << l1, budget)) continue;
                     b.n_ct = (1 << l1) >> b.log2C;
                     const double cost = seg_cost(a.seg_bytes) + seg_cost(m.seg_bytes) + 0.5 + 0.5 * store_cost(b.seg_bytes) +
-                                        0.01 * (abs(l1 - l2) + abs(l2 - l3));
+                                        0.01 * (abs(l1 - l2) + abs(l2 - l3)) - chain_bonus(a, b);
                     if (cost < best_cost) {
                         best_cost = cost;
                         best.clear();
@@ -946,6 +964,68 @@ class Pow2Plan {
         }
     }
 
+    // ---- forward transform -> spectral product -> inverse transform with the forward's LAST pass and the inverse's FIRST
+    // pass as one kernel (fft_kernels_chain.h): possible when both have the same tile
+    int chain_smem() const {
+        const PassDesc &a = passes.front(), &b = passes.back();
+        const int data = (std::max(a.group_bytes, b.group_bytes) + 15) & ~15;
+        return data + (a.tables_elems + b.tables_elems) * SZ + 16;
+    }
+    static constexpr int kChainMinLog2n = 0;  // measured (tools/ab_chain.py, profiles/r2_ab_chain.txt): chaining wins at every size it applies to (2^14 ... 2^21: +7...27 %)
+    int chain_min_log2n = kChainMinLog2n;
+    bool chain_capable() const {
+        if (!hook_capable() || passes.size() < 2 || log2n < chain_min_log2n) return false;
+        const PassDesc &a = passes.front(), &b = passes.back();
+        return a.log2L == b.log2L && a.log2C == b.log2C && a.nthreads == b.nthreads && a.nthreads <= 512 && a.log2H == 0 && b.log2H == 0 && chain_smem() <= rt->max_lds_bytes();
+    }
+    void launch_chain(const cpx<T>* in, cpx<T>* out, int nb, const ExecHooks<T>& h, long long tab_off) {
+        using namespace fftk;
+        const size_t last = passes.size() - 1;
+        const PassDesc &a = passes.front(), &b = passes.back();
+        ChainParams<T> q;
+        q.b = pass_params(last, in, nullptr, nb, false, (T)1);
+        q.a = pass_params(0, nullptr, out, nb, true, (T)1);
+        const int data = (std::max(a.group_bytes, b.group_bytes) + 15) & ~15;
+        q.b.off_tables = data;
+        q.off_tables_a = data + b.tables_elems * SZ;
+        TileHooks<T>& k = q.b.hk;
+        k.n_in = 0x7fffffff; k.n_out = 0x7fffffff; k.in_vec_ok = 1; k.out_vec_ok = 1;
+        k.post_tab = h.post_tab ? h.post_tab + tab_off : nullptr;
+        k.post_tab_b = h.post_tab_b;
+        k.post_mode = (h.post_tab || h.post_mode == HOOK_ABS2) ? h.post_mode : HOOK_NONE;
+        const int smem = chain_smem();
+        int per_cu = rt->max_blocks_per_cu(tile_fft_ba_kernel<T>, a.nthreads, (size_t)smem);
+        if (per_cu < 1) per_cu = 1;
+        long long grid = (long long)rt->num_cus() * per_cu;
+        if (grid > q.b.n_tiles) grid = q.b.n_tiles;
+        rt->launch(tile_fft_ba_kernel<T>, grid, a.nthreads, (size_t)smem, q);
+    }
+    // out = IFFT( post_f( FFT( pre_f(in) ) ) ) with the ends of `hf` (load side + spectral product) and `hi` (store side of
+    // the inverse); requires chain_capable().  One HBM round trip less than execute_hooked twice.
+    bool execute_chain(const cpx<T>* in, cpx<T>* out, int nb, const ExecHooks<T>& hf, const ExecHooks<T>& hi, T extra_scale = (T)1) {
+        const long long n = 1ll << log2n;
+        if (!scratch2) {
+            scratch2 = (cpx<T>*)rt->dmalloc(scratch_bytes);
+            if (!scratch2) return false;
+        }
+        const T scale = (T)((1.0L / (long double)n) * (long double)extra_scale);
+        const long long ip = hf.in_pitch ? hf.in_pitch : n, op = hi.out_pitch ? hi.out_pitch : n;
+        const size_t last = passes.size() - 1;
+        run_if = nullptr;
+        for (int b0 = 0; b0 < nb; b0 += chunk) {
+            const int cb = (nb - b0) < chunk ? (nb - b0) : chunk;
+            launch_pass_hooked(0, in + (size_t)b0 * (size_t)ip, scratch, cb, false, (T)1, hf, 1, 0);
+            rt->mark(0);
+            if (passes.size() == 3) launch_pass(1, scratch, scratch, cb, false, (T)1);
+            launch_chain(scratch, scratch2, cb, hf, (long long)b0 * hf.post_tab_b);
+            rt->mark(1);
+            if (passes.size() == 3) launch_pass(1, scratch2, scratch2, cb, true, (T)1);
+            launch_pass_hooked(last, scratch2, out + (size_t)b0 * (size_t)op, cb, true, scale, hi, 2, (long long)b0 * hi.post_tab_b);
+            rt->mark(2);
+        }
+        return true;
+    }
+
     // execute() with fused element-wise ends; requires hook_capable().  Never the team kernel (it has no hooks).
     void execute_hooked(const cpx<T>* in, cpx<T>* out, int nb, bool inverse, const ExecHooks<T>& h, T extra_scale = (T)1) {
         const long long n = 1ll << log2n;
@@ -1065,6 +1145,7 @@ class BluesteinPlan {
     cpx<T>* work = nullptr;   // max_batch * m
     bool ok = false;
     bool no_fusion = false;   // tests: run the element-wise steps as kernels of their own
+    bool no_chain = false;    // tests: keep the forward transform's last and the inverse's first pass as two kernels
 
     ~BluesteinPlan() {
         if (!rt) return;
@@ -1081,6 +1162,7 @@ class BluesteinPlan {
         long long m = 1;
         while (m < 2ll * n - 1) m <<= 1;
         log2m = ilog2(m);
+        core.prefer_chain = true;  // forward + inverse of length m back to back
         if (!core.build(rt, log2m, algo, batch)) return false;
         std::vector<cpx<T>> c((size_t)n), b((size_t)m);
         const long double pi = 3.141592653589793238462643383279502884L;
@@ -1119,9 +1201,12 @@ class BluesteinPlan {
             ExecHooks<T> f;
             f.pre_tab = chirp; f.pre_mode = fftk::HOOK_MUL_CONJ; f.n_in = n; f.in_pitch = n;
             f.post_tab = bfft; f.post_mode = fftk::HOOK_MUL;
-            core.execute_hooked(in, work, nb, false, f);
             ExecHooks<T> g;
             g.post_tab = chirp; g.post_mode = fftk::HOOK_MUL_CONJ; g.n_out = n; g.out_pitch = n;
+            // the forward transform's last pass and the inverse's first as one kernel where their tiles agree (m = 2^21 fp64:
+            // 128 x 128 x 128): five HBM round trips of the padded image instead of six
+            if (!no_chain && core.chain_capable() && core.execute_chain(in, out, nb, f, g, scale)) return;
+            core.execute_hooked(in, work, nb, false, f);
             core.execute_hooked(work, out, nb, true, g, scale);  // the inverse carries the 1/m
             return;
         }

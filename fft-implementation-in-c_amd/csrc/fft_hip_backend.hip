@@ -878,6 +878,15 @@ int fft_gpu_plan_set_option_hip(fft_gpu_plan_t p, fft_gpu_plan_option_t option, 
             if (p->f32) p->f32->no_fusion = value != 0;
             if (p->f64) p->f64->no_fusion = value != 0;
             return (p->b32 || p->b64 || p->f32 || p->f64) ? 0 : -1;
+        case FFT_GPU_OPT_NO_CHAIN: {  // 0 the planner's rule, 1 never, 2 wherever the tiles agree (tools: the size rule is a measured one)
+            auto set = [&](auto* q) {
+                if (!q) return;
+                q->no_chain = value == 1;
+                q->core.chain_min_log2n = value == 2 ? 0 : std::remove_reference_t<decltype(q->core)>::kChainMinLog2n;
+            };
+            set(p->b32); set(p->b64); set(p->f32); set(p->f64);
+            return (p->b32 || p->b64 || p->f32 || p->f64) ? 0 : -1;
+        }
         default:
             return -1;
     }
@@ -978,13 +987,21 @@ int fft_gpu_plan_info_hip(fft_gpu_plan_t p, fft_gpu_plan_info_t* info) {
     if (p->b32) {
         fill(&p->b32->core);
         info->bluestein_m = 1 << p->b32->log2m;
+        info->fused = (p->b32->core.hook_capable() && !p->b32->no_fusion) ? ((!p->b32->no_chain && p->b32->core.chain_capable()) ? 2 : 1) : 0;
         info->workspace_bytes += (size_t)p->batch * ((size_t)1 << p->b32->log2m) * sizeof(complex32_t);
     }
     if (p->b64) {
         fill(&p->b64->core);
         info->bluestein_m = 1 << p->b64->log2m;
+        info->fused = (p->b64->core.hook_capable() && !p->b64->no_fusion) ? ((!p->b64->no_chain && p->b64->core.chain_capable()) ? 2 : 1) : 0;
         info->workspace_bytes += (size_t)p->batch * ((size_t)1 << p->b64->log2m) * sizeof(complex_t);
     }
+    auto fill_fused = [&](auto* f) {  // fused consumers: the padded transform behind them
+        fill(&f->core);
+        info->fused = f->fused() ? ((!f->no_chain && f->kind != ffteng::FUSED_PSD && f->core.chain_capable()) ? 2 : 1) : 0;
+    };
+    if (p->f32) fill_fused(p->f32);
+    if (p->f64) fill_fused(p->f64);
     return 0;
 }
 

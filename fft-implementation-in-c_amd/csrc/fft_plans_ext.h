@@ -195,6 +195,7 @@ class FusedPlan {
     cpx<T>* work2 = nullptr;  // [batch][m] (XCORR: the spectrum of x)
     bool ok = false;
     bool no_fusion = false;   // tests: element-wise steps as kernels of their own
+    bool no_chain = false;    // tests: forward-last and inverse-first pass as two kernels
     ~FusedPlan() {
         if (!rt) return;
         rt->dfree(H); rt->dfree(work); rt->dfree(work2);
@@ -230,6 +231,7 @@ class FusedPlan {
         }
         if (mm > (1ll << 29)) return false;
         log2m = ilog2(mm);
+        core.prefer_chain = kind != FUSED_PSD;  // forward + inverse back to back (the periodogram has no inverse)
         if (!core.build(rt, log2m, ALGO_AUTO, batch)) return false;
         work = (cpx<T>*)rt->dmalloc((size_t)batch * (size_t)mm * SZ);
         if (!work) return false;
@@ -302,23 +304,33 @@ class FusedPlan {
                    (int)fftk::HOOK_NONE, out, out_pitch, n_out, (T)1, bpr);
     }
 
+    // forward + spectral product + inverse in one go; the middle of it as ONE kernel where the plan allows (execute_chain)
+    void forward_inverse(const cpx<T>* in, int n_in, const cpx<T>* tab, long long tab_b, int post_mode, cpx<T>* out, int n_out, int nb) {
+        if (fused() && !no_chain && core.chain_capable()) {
+            ExecHooks<T> f, g;
+            f.n_in = n_in; f.in_pitch = n_in;
+            f.post_tab = tab; f.post_tab_b = tab_b; f.post_mode = post_mode;
+            g.n_out = n_out; g.out_pitch = n_out;
+            if (core.execute_chain(in, out, nb, f, g)) return;
+        }
+        forward(in, n_in, n_in, nullptr, work, tab, tab_b, post_mode, nb);
+        inverse(work, out, n_out, n_out, nb);
+    }
+
     // x: [nb][nx]; y: second input of XCORR ([nb][nx]), else unused; out: [nb][out_len()] complex
     // (PSD: out is [nb][nx/2 + 1] REAL values of type T, sample_rate scales it)
     void execute(const cpx<T>* x, const cpx<T>* y, void* out, int nb, T sample_rate = (T)1) {
         switch (kind) {
             case FUSED_CONV_LINEAR:
             case FUSED_CONV_CIRCULAR:
-                forward(x, nx, nx, nullptr, work, H, 0, fftk::HOOK_MUL, nb);
-                inverse(work, (cpx<T>*)out, ny, ny, nb);
+                forward_inverse(x, nx, H, 0, fftk::HOOK_MUL, (cpx<T>*)out, ny, nb);
                 break;
             case FUSED_AUTOCORR:
-                forward(x, nx, nx, nullptr, work, nullptr, 0, fftk::HOOK_ABS2, nb);
-                inverse(work, (cpx<T>*)out, ny, ny, nb);
+                forward_inverse(x, nx, nullptr, 0, fftk::HOOK_ABS2, (cpx<T>*)out, ny, nb);
                 break;
             case FUSED_XCORR:
-                forward(x, nx, nx, nullptr, work2, nullptr, 0, fftk::HOOK_NONE, nb);        // X
-                forward(y, nx, nx, nullptr, work, work2, m(), fftk::HOOK_MUL_CONJ, nb);    // Y conj(X)
-                inverse(work, (cpx<T>*)out, ny, ny, nb);
+                forward(x, nx, nx, nullptr, work2, nullptr, 0, fftk::HOOK_NONE, nb);                    // X
+                forward_inverse(y, nx, work2, m(), fftk::HOOK_MUL_CONJ, (cpx<T>*)out, ny, nb);           // IFFT(Y conj(X))
                 break;
             case FUSED_PSD: {
                 forward(x, nx, nx, H, work, nullptr, 0, fftk::HOOK_NONE, nb);

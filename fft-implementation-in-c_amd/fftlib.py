@@ -28,7 +28,7 @@ class PlanInfo(C.Structure):
     _fields_ = [("n", C.c_int), ("batch", C.c_int), ("direction", C.c_int), ("precision", C.c_int),
                 ("algo", C.c_int), ("device", C.c_int), ("bluestein_m", C.c_int), ("n_passes", C.c_int),
                 ("factors", C.c_int * 4), ("chunk_batch", C.c_int), ("workspace_bytes", C.c_size_t),
-                ("team_tiles", C.c_int)]
+                ("team_tiles", C.c_int), ("fused", C.c_int)]
 
 
 # every symbol include/*.h declares, with its ctypes signature
@@ -136,7 +136,7 @@ def init():
 
 
 EXP_LIB_PATH = os.path.join(HERE, "libfft_mi355x_exp.so")  # -DFFT_EXPERIMENTS build: kernel-variant switches, ablation bits
-OPT_TEAM_FORCE_FALLBACK, OPT_TEAM_ENABLE, OPT_NO_FUSION = 1, 2, 3
+OPT_TEAM_FORCE_FALLBACK, OPT_TEAM_ENABLE, OPT_NO_FUSION, OPT_NO_CHAIN = 1, 2, 3, 4
 
 
 def set_policy(team=-1, min_batch=-1, chunk_mb=-1):
@@ -281,6 +281,11 @@ class ExtPlan:
     def set_option(self, option, value):
         if self.lib.fft_gpu_plan_set_option_hip(self.handle, option, value) != 0:
             raise RuntimeError("fft_gpu_plan_set_option_hip(%d) failed" % option)
+
+    def info(self):
+        pi = PlanInfo()
+        self.lib.fft_gpu_plan_info(self.handle, C.byref(pi))
+        return pi
 
     def execute_fused(self, d_x, d_y, d_out, sample_rate=1.0):
         if self.lib.fft_gpu_execute_fused_hip(self.handle, d_x, d_y, d_out, sample_rate) != 0:

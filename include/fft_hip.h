@@ -85,6 +85,9 @@ typedef struct {
     int team_tiles;     /* 0: multi-pass schedule only.  1/2/4: the plan runs the one-round-trip team kernel (a whole
                            transform per XCD, this many 64 KiB tiles per workgroup); the multi-pass schedule
                            described by n_passes/factors is queued behind it as its fallback */
+    int fused;          /* Bluestein and fused-consumer plans: 0 the element-wise steps run as kernels of their own, 1 they
+                           ride on the first load / last store of the transforms, 2 and the forward transform's last pass and
+                           the inverse's first pass are ONE kernel (2 * n_passes - 1 launches per group of chunk_batch) */
 } fft_gpu_plan_info_t;
 
 /* Per-plan switches (tests and integrators; nothing here changes results) */
@@ -92,8 +95,11 @@ typedef enum {
     FFT_GPU_OPT_TEAM_FORCE_FALLBACK = 1, /* 1: the team kernel behaves as if it could not form its XCD teams (status 1, nothing
                                             touched) and the multi-pass plan queued behind it does the work */
     FFT_GPU_OPT_TEAM_ENABLE = 2,         /* 0: run the multi-pass schedule only; 1: back to the team kernel where the plan has one */
-    FFT_GPU_OPT_NO_FUSION = 3            /* 1: Bluestein / fused-consumer plans run their element-wise steps as kernels of their own
+    FFT_GPU_OPT_NO_FUSION = 3,           /* 1: Bluestein / fused-consumer plans run their element-wise steps as kernels of their own
                                             instead of fusing them into the FFT passes (same results to rounding; tests) */
+    FFT_GPU_OPT_NO_CHAIN = 4             /* 1: Bluestein / fused-consumer plans keep the forward transform's last pass and the inverse
+                                            transform's first pass as two kernels (by default they run as one where their tiles agree
+                                            and the transform has >= 2^19 points; tests); 2: as one wherever the tiles agree (tools) */
 } fft_gpu_plan_option_t;
 
 /* Fused consumers of the transform (reference applications/convolution.c, applications/power_spectrum.c): FFT ->

@@ -134,9 +134,12 @@ static int run(const void* in, void* out, int n, int batch, int dir, int algo, i
         ffteng::BluesteinPlan<T, emu::Runtime> plan;
         if (!plan.build(&rt, n, dir, algo, batch)) return -1;
         if (getenv("FFT_EMU_NO_FUSION")) plan.no_fusion = true;
+        if (getenv("FFT_EMU_NO_CHAIN")) plan.no_chain = true;
+        plan.core.chain_min_log2n = 0;  // the emulated sizes are small: every plan whose tiles agree chains
         if (info) {
             info[0] = 10 + (int)plan.core.passes.size();
             info[4] = (plan.core.hook_capable() && !plan.no_fusion) ? 1 : 0;  // element-wise steps fused into the FFT passes
+            if (info[4] && !plan.no_chain && plan.core.chain_capable()) info[4] = 2;  // ... and forward-last + inverse-first as one kernel
         }
         plan.execute((const C*)in, (C*)out, batch);
     }
@@ -203,9 +206,11 @@ static int run_fused(int kind, const void* x, const void* y, const void* h, int 
     ffteng::FusedPlan<T, emu::Runtime> plan;
     if (!plan.build(&rt, kind, nx, nh, (const fftk::cpx<T>*)h, batch)) return -1;
     plan.no_fusion = no_fusion != 0;
+    if (getenv("FFT_EMU_NO_CHAIN")) plan.no_chain = true;
+    plan.core.chain_min_log2n = 0;
     if (info) {
         info[0] = (int)plan.core.passes.size();
-        info[1] = plan.fused() ? 1 : 0;
+        info[1] = plan.fused() ? ((!plan.no_chain && plan.core.chain_capable() && kind != ffteng::FUSED_PSD) ? 2 : 1) : 0;
         info[2] = plan.log2m;
     }
     plan.execute((const fftk::cpx<T>*)x, (const fftk::cpx<T>*)y, out, batch, (T)fs);

@@ -97,17 +97,20 @@ def test_bluestein_emulated():
             assert rel(y, O.oracle_fft(x, d, "bluestein")) < 1e-12
 
 
-@pytest.mark.parametrize("n,dtype,lds,passes", [
-    (100, np.complex64, 0, 1),        # single-pass hooks, fp32 pairs, even pitch
-    (101, np.complex64, 0, 1),        # odd pitch: the user's rows are not 16-byte aligned -> value-by-value accesses
-    (1009, np.complex64, 0, 1),       # m = 2048, odd n: the last pair straddles n
-    (1009, np.complex128, 4096, 2),   # m = 2048 in two passes: load hook on the column pass, store hooks on the row pass
-    (1009, np.complex64, 4096, 2),
-    (1500, np.complex64, 4096, 3),     # m = 4096
-    (3001, np.complex128, 2048, 3),   # m = 8192 in three passes
-    (3001, np.complex64, 2048, 3),
+@pytest.mark.parametrize("n,dtype,lds,passes,chained", [
+    (100, np.complex64, 0, 1, 0),        # single-pass hooks, fp32 pairs, even pitch
+    (101, np.complex64, 0, 1, 0),        # odd pitch: the user's rows are not 16-byte aligned -> value-by-value accesses
+    (1009, np.complex64, 0, 1, 0),       # m = 2048, odd n: the last pair straddles n
+    (1009, np.complex128, 4096, 2, 0),   # m = 2048 in two passes: load hook on the column pass, store hooks on the row pass
+    (1009, np.complex64, 4096, 2, 0),
+    (1500, np.complex64, 4096, 3, 1),    # m = 4096 = 16 x 16 x 16: the forward's last pass and the inverse's first share a tile
+    (3001, np.complex128, 2048, 3, 0),   # m = 8192 in three passes
+    (3001, np.complex64, 2048, 3, 1),    # 16 x 32 x 16: a split with equal ends is preferred (Pow2Plan::prefer_chain)
+    (2000, np.complex128, 40000, 2, 1),  # m = 4096 = 64 x 64, two passes, chained (tile-major scratch of the inverse)
+    (2000, np.complex64, 40000, 2, 1),
+    (5000, np.complex128, 4096, 3, 0),   # m = 16384 = 16 x 32 x 32: first and last tiles differ, no chaining
 ])
-def test_bluestein_fused_ends(n, dtype, lds, passes, monkeypatch):
+def test_bluestein_fused_ends(n, dtype, lds, passes, chained, monkeypatch):
     """Bluestein with its modulate / pointwise / demodulate steps fused into the first load and last store of the two
     power-of-two transforms (fftk::TileHooks) against the oracle, and bit-for-bit ... no: to rounding ... against the
     same plan run with the three steps as kernels of their own."""
@@ -117,8 +120,15 @@ def test_bluestein_fused_ends(n, dtype, lds, passes, monkeypatch):
     for d in (-1, 1):
         for inplace in (False, True):
             y, info = E.emu_fft(x, d, lds_budget=lds, inplace=inplace)
-            assert info[0] == 10 + passes and info[4] == 1, info[:5]
+            # info[4]: 1 fused ends, 2 also the forward's last and the inverse's first pass as ONE kernel (fft_kernels_chain.h)
+            assert info[0] == 10 + passes and info[4] == 1 + chained, info[:5]
             assert rel(y, O.oracle_fft(x.astype(np.complex128), d, "bluestein")) < tol, (n, d, inplace)
+    if chained:
+        monkeypatch.setenv("FFT_EMU_NO_CHAIN", "1")
+        y1, info = E.emu_fft(x, -1, lds_budget=lds)
+        assert info[4] == 1
+        assert rel(y1, y.astype(np.complex128) if d == -1 else E.emu_fft(x, -1, lds_budget=lds)[0].astype(np.complex128)) < tol
+        monkeypatch.delenv("FFT_EMU_NO_CHAIN")
     monkeypatch.setenv("FFT_EMU_NO_FUSION", "1")
     y2, info = E.emu_fft(x, -1, lds_budget=lds)
     assert info[4] == 0

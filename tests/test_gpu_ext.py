@@ -171,6 +171,9 @@ def test_correlations_and_periodogram_vs_reference_golden(gpu_lib, n):
     ("autocorr", 20000, 0, 6, np.complex64), ("autocorr", 3333, 0, 6, np.complex128),
     ("xcorr", 20001, 0, 6, np.complex64), ("xcorr", 70000, 0, 3, np.complex128),
     ("psd", 1 << 16, 0, 8, np.complex64), ("psd", 4096, 0, 8, np.complex128),
+    # transforms of 2^20 / 2^21 points: forward-last + inverse-first pass chained (csrc/fft_kernels_chain.h), two- and three-pass
+    ("conv", 1 << 19, 1000, 3, np.complex64), ("circ", 1 << 20, 0, 2, np.complex64), ("circ", 1 << 21, 0, 2, np.complex128),
+    ("autocorr", 1 << 19, 0, 2, np.complex128), ("xcorr", 1 << 19, 0, 2, np.complex64),
 ])
 def test_fused_consumers_batched_vs_oracle(gpu_lib, kind, nx, nh, batch, dtype):
     """Device-resident, batched plans (fft_gpu_plan_fused_hip): fused and with the element-wise steps as kernels of
@@ -188,8 +191,11 @@ def test_fused_consumers_batched_vs_oracle(gpu_lib, kind, nx, nh, batch, dtype):
         bufs[1].upload(y)
     out = fftlib.DeviceBuffer(batch * plan.out_len * np.dtype(rdt).itemsize)
     results = []
-    for no_fusion in (0, 1):
+    for no_fusion, no_chain in ((0, 0), (1, 0), (0, 1)):
         plan.set_option(fftlib.OPT_NO_FUSION, no_fusion)
+        plan.set_option(fftlib.OPT_NO_CHAIN, no_chain)
+        fused = plan.info().fused  # 2: the middle two passes as one kernel (transforms of >= 2^19 points whose end tiles agree)
+        assert fused == 0 if no_fusion else (fused == 1 if no_chain else fused in (1, 2)), (kind, nx, fused)
         plan.execute_fused(bufs[0].ptr, bufs[1].ptr if y is not None else None, out.ptr, 48000.0)
         assert plan.sync() == 0
         results.append(out.download((batch, plan.out_len), rdt))
@@ -203,14 +209,15 @@ def test_fused_consumers_batched_vs_oracle(gpu_lib, kind, nx, nh, batch, dtype):
     for res in results:
         r = rel(res[pick], ref)
         assert r <= TOL[np.dtype(dtype)] and r <= TIGHT[np.dtype(dtype)] * 16, (kind, nx, r)
-    assert rel(results[0], results[1].astype(np.complex128)) <= TIGHT[np.dtype(dtype)] * 16  # every transform of the batch
+    for other in results[1:]:
+        assert rel(results[0], other.astype(np.complex128)) <= TIGHT[np.dtype(dtype)] * 16  # every transform of the batch
     plan.destroy()
     for b in bufs + [out]:
         b.free()
 
 
 @pytest.mark.parametrize("n,batch,dtype", [(1009, 7, np.complex128), (1009, 7, np.complex64), (100003, 3, np.complex128),
-                                           (100003, 3, np.complex64), (3000017, 1, np.complex128), (1000, 33, np.complex64)])
+                                           (100003, 3, np.complex64), (1000003, 2, np.complex128), (3000017, 1, np.complex128), (1000, 33, np.complex64)])
 def test_bluestein_fused_equals_unfused_and_oracle(gpu_lib, n, batch, dtype):
     import fftlib
     x = lcg((batch, n), n, dtype)
@@ -218,8 +225,13 @@ def test_bluestein_fused_equals_unfused_and_oracle(gpu_lib, n, batch, dtype):
     for d in (-1, 1):
         plan = fftlib.Plan(n, batch, d, dtype)
         res = []
-        for no_fusion in (0, 1):
+        for no_fusion, no_chain in ((0, 0), (1, 0), (0, 1)):
             plan.set_option(fftlib.OPT_NO_FUSION, no_fusion)
+            plan.set_option(fftlib.OPT_NO_CHAIN, no_chain)
+            fused = plan.info().fused
+            # m = 2^18 = 512 x 512, 2^21 = 128^3, 2^23 = 256 x 128 x 256: the planner picks splits whose end tiles agree, those chain;
+            # m = 2048 is a single pass
+            assert fused == (0 if no_fusion else 1 if (no_chain or n < 100000) else 2), (n, fused)
             buf.upload(x)
             plan.execute_ptr(buf.ptr, buf.ptr)  # in place: the user's array is both the first load and the last store
             assert plan.sync() == 0
@@ -230,7 +242,8 @@ def test_bluestein_fused_equals_unfused_and_oracle(gpu_lib, n, batch, dtype):
         # restates it, so the fp64 bound against it is loosened with n; fused vs unfused below stays tight
         tight = max(TIGHT[np.dtype(dtype)] * 16, 1e-15 * n)
         assert r <= TOL[np.dtype(dtype)] and r <= tight, (n, d, r)
-        assert rel(res[0], res[1].astype(np.complex128)) <= TIGHT[np.dtype(dtype)] * 16
+        for other in res[1:]:
+            assert rel(res[0], other.astype(np.complex128)) <= TIGHT[np.dtype(dtype)] * 16
         plan.destroy()
     buf.free()
 
