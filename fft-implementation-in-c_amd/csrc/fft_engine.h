@@ -619,7 +619,10 @@ class Pow2Plan {
                 b.in_blk_bits = a.log2C;   // n2 -> block n2 / C_A, column n2 % C_A
                 b.in_blk_stride = CA << l1;
             }
-            const double cost = seg_cost(a.seg_bytes) + 0.5 + 0.5 * store_cost(b.seg_bytes) + 0.01 * abs(l1 - l2) - chain_bonus(a, b);
+            // where tools/split_sweep.py (profiles/r2_split_sweep.txt) measured another two-pass split 3...8 % faster than the model's
+            // pick on MI355X, the measurement wins: 2^17 = 256 x 512, 2^18 = 512 x 512, 2^19 = 1024 x 512 (both precisions)
+            const double measured = ((log2n == 17 && l1 == 8) || (log2n == 18 && l1 == 9) || (log2n == 19 && l1 == 10)) ? 0.4 : 0.0;
+            const double cost = seg_cost(a.seg_bytes) + 0.5 + 0.5 * store_cost(b.seg_bytes) + 0.01 * abs(l1 - l2) - chain_bonus(a, b) - measured;
             if (cost < best_cost) {
                 best_cost = cost;
                 best.clear();
