@@ -90,6 +90,10 @@ bool test_drop();   // test hook: this workgroup leaves right after the team has
 #define FFT_DMA16_L2_NT(gsrc, lds_base_ptr, lds_base_addr, off) memcpy((lds_base_ptr) + (off), (gsrc), 16)
 #define FFT_STORE16_NT(ptr, v) (*(ptr) = (v))
 #define FFT_STORE16_SC1(ptr, v) (*(ptr) = (v))
+template <int NT, class V16>
+inline V16 fft_ld16(const V16* p) { return *p; }
+template <int NT, class V16>
+inline void fft_st16(V16* p, const V16& v) { *p = v; }
 #define FFT_WAIT_VM_LE(n) __atomic_thread_fence(__ATOMIC_SEQ_CST)
 #else
 #include <hip/hip_runtime.h>
@@ -209,6 +213,30 @@ __device__ __forceinline__ void fft_store16_nt(V16* ptr, const V16& v) {
     __builtin_memcpy(&raw, &v, 16);
     // hand-written: __builtin_nontemporal_store of a 16-byte vector comes out as a plain global_store_dwordx4 here
     asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(ptr), "v"(raw) : "memory");
+}
+// 16-byte accesses of the tile kernels' HBM streams, optionally with the non-temporal hint (NT != 0): through the clang
+// builtins on a 4 x 32-bit vector, which hipcc tracks in its own s_waitcnt bookkeeping (global_load_dwordx4 ... nt)
+template <int NT, class V16>
+__device__ __forceinline__ V16 fft_ld16(const V16* p) {
+    static_assert(sizeof(V16) == 16, "one 16-byte lane access");
+    if (NT) {
+        const fft_u32x4 raw = __builtin_nontemporal_load(reinterpret_cast<const fft_u32x4*>(p));
+        V16 v;
+        __builtin_memcpy(&v, &raw, 16);
+        return v;
+    }
+    return *p;
+}
+template <int NT, class V16>
+__device__ __forceinline__ void fft_st16(V16* p, const V16& v) {
+    static_assert(sizeof(V16) == 16, "one 16-byte lane access");
+    if (NT) {
+        fft_u32x4 raw;
+        __builtin_memcpy(&raw, &v, 16);
+        __builtin_nontemporal_store(raw, reinterpret_cast<fft_u32x4*>(p));
+    } else {
+        *p = v;
+    }
 }
 // 16-byte store written through and NOT kept in the L2 (sc1: MI355X_MICROARCH.md, "stores of each flavour")
 #define FFT_STORE16_SC1(ptr, v) fft_store16_sc1((ptr), (v))

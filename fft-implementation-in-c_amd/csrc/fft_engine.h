@@ -893,6 +893,15 @@ class Pow2Plan {
             tp.tiles_per_b = p.n_o * p.n_ct;
         }
         tp.pair16 = (pair16 && ((1ll << p.log2C) * SZ < 128)) ? 1 : 0;
+        {   // non-temporal hint on the HBM streams of plans whose every strided side moves whole 128-byte lines (TileParams::nt;
+            // profiles/r2_ab_tile_nt.txt: +5 % at n = 64, +10 % on the two-pass 2^16, +2...5 % on 2^21, 2^22; a plan with 64-byte
+            // row segments -- L = 1024 column passes -- loses 6...20 % with the hint on any of its passes and gets none)
+            static const int nt_force = FFT_EXP_ENV("FFT_HIP_TILE_NT") ? atoi(FFT_EXP_ENV("FFT_HIP_TILE_NT")) : -1;
+            bool wide = true;
+            for (const PassDesc& q : passes)
+                if (q.n_cols >= 0 && (1ll << q.log2C) * SZ < 128) wide = false;
+            tp.nt = nt_force >= 0 ? nt_force : (wide ? 3 : 0);
+        }
         if (p.n_cols < 0) {  // single-pass row kernel: columns are the transforms of the batch
             tp.n_cols = nb;
             tp.n_ct = (int)((nb + (1ll << p.log2C) - 1) >> p.log2C);

@@ -13,6 +13,7 @@
 // >= 64..128-byte contiguous segment, that the data makes exactly one HBM round
 // trip per pass, and that twiddles come from LDS.
 #pragma once
+#include <type_traits>
 
 #include "fft_codelets.h"
 
@@ -23,6 +24,9 @@ namespace fftk {
 #endif
 #ifndef FFT_FORCE_OPAQUE
 #define FFT_FORCE_OPAQUE 0
+#endif
+#ifndef FFT_TILE_NT
+#define FFT_TILE_NT 3  // which of TileParams::nt's bits the build honours (non-temporal hint: bit 0 data loads, bit 1 result stores)
 #endif
 #ifndef FFT_WAVES_PER_SIMD_E4
 #define FFT_WAVES_PER_SIMD_E4 4
@@ -99,6 +103,9 @@ struct TileParams {
     int tiles_per_b;
     int pair16;   // tile order: pair half-line neighbours on one XCD (see tile_coord)
     int ablate;   // profiling only (FFT_HIP_ABLATE): 1 skip inter-pass twiddle, 2 skip stages
+    int nt;       // non-temporal hint on the pass's HBM streams: bit 0 data loads, bit 1 result stores.  The planner sets a bit
+                  // where the side moves whole 128-byte lines (measured: +5 % at n = 64, +13 % on 128^3 fp64; with 64-byte row
+                  // segments the hint throws away the half line the neighbouring tile is about to ask for: -6...12 %)
     // not NULL: this launch is the fallback behind a team kernel (fft_team.h) and runs only if that kernel left
     // TEAM_STATUS_NO_TEAMS (1) in the word, i.e. gave up before touching anything
     const unsigned* run_if;
@@ -460,6 +467,7 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2((E == 4 ? 1024 : 512), (E == 4 ? FFT_WAVES_PE
     const int tid_invariant = FFT_TID;
     const int tid = tid_invariant;
     const int nthreads = FFT_NTHREADS;
+    const bool nt_load = (p.nt & FFT_TILE_NT & 1) != 0, nt_store = (p.nt & FFT_TILE_NT & 2) != 0;
     const int log2L = FIXED ? (FIXED >> 8) : p.log2L;
     const int log2C = FIXED ? (FIXED & 255) : p.log2C;
     const int L = 1 << log2L;
@@ -509,7 +517,9 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2((E == 4 ? 1024 : 512), (E == 4 ? FFT_WAVES_PE
         if (LOADM == LOAD_CCONTIG) return tc.iidx + (long long)(r + ((long long)i << log2TPC)) * p.in_l + tc.c0 + h * CG + V * j;
         return (long long)(((tid + i * nthreads) & cpr_mask) * V);
     };
-    auto prefetch = [&](long long tile, vec16<T> (&nxt)[H][E], vec16<T> (&ntab)[HK_TABPF ? H : 1][HK_TABPF ? E : 1]) __attribute__((always_inline)) {
+    // (generic on the non-temporal bit: ONE wave-uniform branch per tile, the loads of a tile stay one clause)
+    auto prefetch_as = [&](auto nt_tag, long long tile, vec16<T> (&nxt)[H][E], vec16<T> (&ntab)[HK_TABPF ? H : 1][HK_TABPF ? E : 1]) __attribute__((always_inline)) {
+        constexpr int NTL = decltype(nt_tag)::value;
         const TileCoord<T> tc = tile_coord(p, tile);
         int r = r_invariant, j = j_invariant, tid = tid_invariant;
         if (E * H >= 16 || FFT_WAVES_PER_SIMD >= 4 || FFT_FORCE_OPAQUE) {
@@ -544,7 +554,7 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2((E == 4 ? 1024 : 512), (E == 4 ? FFT_WAVES_PE
                     for (int vv = 0; vv < V; vv++) nxt[h][i].c[vv] = mk<T>((T)0, (T)0);
                     if (live && idx0 < n_in) {
                         if (p.hk.in_vec_ok && idx0 + V <= n_in) {
-                            nxt[h][i] = *reinterpret_cast<const vec16<T>*>(src);
+                            nxt[h][i] = fft_ld16<NTL>(reinterpret_cast<const vec16<T>*>(src));
                         } else {
                             FFT_UNROLL
                             for (int vv = 0; vv < V; vv++)
@@ -553,13 +563,17 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2((E == 4 ? 1024 : 512), (E == 4 ? FFT_WAVES_PE
                         if (HK_TABPF && pre_on) ntab[HK_TABPF ? h : 0][HK_TABPF ? i : 0] = *reinterpret_cast<const vec16<T>*>(p.hk.pre_tab + idx0);  // table padded to a multiple of V
                     }
                 } else if (live) {
-                    nxt[h][i] = *reinterpret_cast<const vec16<T>*>(src);
+                    nxt[h][i] = fft_ld16<NTL>(reinterpret_cast<const vec16<T>*>(src));
                 } else {
                     FFT_UNROLL
                     for (int vv = 0; vv < V; vv++) nxt[h][i].c[vv] = mk<T>((T)0, (T)0);
                 }
             }
         }
+    };
+    auto prefetch = [&](long long tile, vec16<T> (&nxt)[H][E], vec16<T> (&ntab)[HK_TABPF ? H : 1][HK_TABPF ? E : 1]) __attribute__((always_inline)) {
+        if (nt_load) prefetch_as(std::integral_constant<int, 1>{}, tile, nxt, ntab);
+        else prefetch_as(std::integral_constant<int, 0>{}, tile, nxt, ntab);
     };
     // load-side product, applied to the landed chunks (zero samples stay zero whatever the stale table register holds)
     auto apply_pre = [&](vec16<T> (&nxt)[H][E], vec16<T> (&ntab)[HK_TABPF ? H : 1][HK_TABPF ? E : 1], const TileCoord<T>& tc, int r, int j, int tid) __attribute__((always_inline)) {
@@ -743,87 +757,92 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2((E == 4 ? 1024 : 512), (E == 4 ? FFT_WAVES_PE
             const cpx<T> w = tb[idx];
             return p.hk.post_mode == HOOK_MUL_CONJ ? cmul_conj(v, w) : cmul(v, w);
         };
-        if (STOREM == STORE_CCONTIG) {
-            const cpx<T>* tb = HK_STORE ? p.hk.post_tab + tc.b * p.hk.post_tab_b : nullptr;
-            FFT_UNROLL
-            for (int e = 0; e < E; e++) {
-                const long long K = r + ((long long)e << log2TPC);
-                FFT_UNROLL
-                for (int h = 0; h < H; h++) {
-                    if ((tc.c0 + h * CG + V * j) < p.n_cols) {
-                        vec16<T> v;
-                        FFT_UNROLL
-                        for (int vv = 0; vv < V; vv++) v.c[vv] = x[h][e][vv];
-                        cpx<T>* dst = tc.out + K * p.out_k + h * CG + V * j;
-                        if (HK_STORE) {
-                            const long long idx0 = tc.oidx + K * p.out_k + tc.c0 + h * CG + V * j;
-                            if (idx0 < p.hk.n_out) {
-                                if (post_on) {
-                                    FFT_UNROLL
-                                    for (int vv = 0; vv < V; vv++)
-                                        if (idx0 + vv < p.hk.n_out) v.c[vv] = post_op(v.c[vv], tb, idx0 + vv);
-                                }
-                                if (p.hk.out_vec_ok && idx0 + V <= p.hk.n_out) {
-                                    *reinterpret_cast<vec16<T>*>(dst) = v;
-                                } else {
-                                    FFT_UNROLL
-                                    for (int vv = 0; vv < V; vv++)
-                                        if (idx0 + vv < p.hk.n_out) dst[vv] = v.c[vv];
-                                }
-                            }
-                        } else {
-                            *reinterpret_cast<vec16<T>*>(dst) = v;
-                        }
-                    }
-                }
-            }
-        } else {
-            FFT_SYNC_LDS();  // last exchange fully consumed
-            FFT_UNROLL
-            for (int h = 0; h < H; h++) {
+        auto store_as = [&](auto nt_tag) __attribute__((always_inline)) {
+            constexpr int NTS = decltype(nt_tag)::value;
+            if (STOREM == STORE_CCONTIG) {
+                const cpx<T>* tb = HK_STORE ? p.hk.post_tab + tc.b * p.hk.post_tab_b : nullptr;
                 FFT_UNROLL
                 for (int e = 0; e < E; e++) {
-                    const int K = r + (e << log2TPC);
+                    const long long K = r + ((long long)e << log2TPC);
                     FFT_UNROLL
-                    for (int vv = 0; vv < V; vv++)
-                        *reinterpret_cast<cpx<T>*>(smem + h * group_bytes + (size_t)(V * j + vv) * pitch + (size_t)K * SZ) = x[h][e][vv];
-                }
-            }
-            FFT_SYNC_LDS();
-            FFT_UNROLL
-            for (int h = 0; h < H; h++) {
-                FFT_UNROLL
-                for (int i = 0; i < E; i++) {
-                    const int g = tid + i * nthreads;
-                    const int t = h * CG + (g >> log2CPR);
-                    const int pos = g & cpr_mask;
-                    if (tc.c0 + t < p.n_cols) {
-                        vec16<T> v = *reinterpret_cast<const vec16<T>*>(smem + h * group_bytes + (size_t)(g >> log2CPR) * pitch + (size_t)pos * 16);
-                        cpx<T>* dst = tc.out + (long long)t * p.out_c + (long long)pos * V;
-                        if (HK_STORE) {  // the single-pass kernel's transforms are its columns: transform index = c0 + t
-                            const long long idx0 = (long long)pos * V;
-                            const cpx<T>* tb = p.hk.post_tab + (long long)(tc.c0 + t) * p.hk.post_tab_b;
-                            if (idx0 < p.hk.n_out) {
-                                if (post_on) {
-                                    FFT_UNROLL
-                                    for (int vv = 0; vv < V; vv++)
-                                        if (idx0 + vv < p.hk.n_out) v.c[vv] = post_op(v.c[vv], tb, idx0 + vv);
+                    for (int h = 0; h < H; h++) {
+                        if ((tc.c0 + h * CG + V * j) < p.n_cols) {
+                            vec16<T> v;
+                            FFT_UNROLL
+                            for (int vv = 0; vv < V; vv++) v.c[vv] = x[h][e][vv];
+                            cpx<T>* dst = tc.out + K * p.out_k + h * CG + V * j;
+                            if (HK_STORE) {
+                                const long long idx0 = tc.oidx + K * p.out_k + tc.c0 + h * CG + V * j;
+                                if (idx0 < p.hk.n_out) {
+                                    if (post_on) {
+                                        FFT_UNROLL
+                                        for (int vv = 0; vv < V; vv++)
+                                            if (idx0 + vv < p.hk.n_out) v.c[vv] = post_op(v.c[vv], tb, idx0 + vv);
+                                    }
+                                    if (p.hk.out_vec_ok && idx0 + V <= p.hk.n_out) {
+                                        fft_st16<NTS>(reinterpret_cast<vec16<T>*>(dst), v);
+                                    } else {
+                                        FFT_UNROLL
+                                        for (int vv = 0; vv < V; vv++)
+                                            if (idx0 + vv < p.hk.n_out) dst[vv] = v.c[vv];
+                                    }
                                 }
-                                if (p.hk.out_vec_ok && idx0 + V <= p.hk.n_out) {
-                                    *reinterpret_cast<vec16<T>*>(dst) = v;
-                                } else {
-                                    FFT_UNROLL
-                                    for (int vv = 0; vv < V; vv++)
-                                        if (idx0 + vv < p.hk.n_out) dst[vv] = v.c[vv];
-                                }
+                            } else {
+                                fft_st16<NTS>(reinterpret_cast<vec16<T>*>(dst), v);
                             }
-                        } else {
-                            *reinterpret_cast<vec16<T>*>(dst) = v;
+                        }
+                    }
+                }
+            } else {
+                FFT_SYNC_LDS();  // last exchange fully consumed
+                FFT_UNROLL
+                for (int h = 0; h < H; h++) {
+                    FFT_UNROLL
+                    for (int e = 0; e < E; e++) {
+                        const int K = r + (e << log2TPC);
+                        FFT_UNROLL
+                        for (int vv = 0; vv < V; vv++)
+                            *reinterpret_cast<cpx<T>*>(smem + h * group_bytes + (size_t)(V * j + vv) * pitch + (size_t)K * SZ) = x[h][e][vv];
+                    }
+                }
+                FFT_SYNC_LDS();
+                FFT_UNROLL
+                for (int h = 0; h < H; h++) {
+                    FFT_UNROLL
+                    for (int i = 0; i < E; i++) {
+                        const int g = tid + i * nthreads;
+                        const int t = h * CG + (g >> log2CPR);
+                        const int pos = g & cpr_mask;
+                        if (tc.c0 + t < p.n_cols) {
+                            vec16<T> v = *reinterpret_cast<const vec16<T>*>(smem + h * group_bytes + (size_t)(g >> log2CPR) * pitch + (size_t)pos * 16);
+                            cpx<T>* dst = tc.out + (long long)t * p.out_c + (long long)pos * V;
+                            if (HK_STORE) {  // the single-pass kernel's transforms are its columns: transform index = c0 + t
+                                const long long idx0 = (long long)pos * V;
+                                const cpx<T>* tb = p.hk.post_tab + (long long)(tc.c0 + t) * p.hk.post_tab_b;
+                                if (idx0 < p.hk.n_out) {
+                                    if (post_on) {
+                                        FFT_UNROLL
+                                        for (int vv = 0; vv < V; vv++)
+                                            if (idx0 + vv < p.hk.n_out) v.c[vv] = post_op(v.c[vv], tb, idx0 + vv);
+                                    }
+                                    if (p.hk.out_vec_ok && idx0 + V <= p.hk.n_out) {
+                                        fft_st16<NTS>(reinterpret_cast<vec16<T>*>(dst), v);
+                                    } else {
+                                        FFT_UNROLL
+                                        for (int vv = 0; vv < V; vv++)
+                                            if (idx0 + vv < p.hk.n_out) dst[vv] = v.c[vv];
+                                    }
+                                }
+                            } else {
+                                fft_st16<NTS>(reinterpret_cast<vec16<T>*>(dst), v);
+                            }
                         }
                     }
                 }
             }
-        }
+        };
+        if (nt_store) store_as(std::integral_constant<int, 1>{});
+        else store_as(std::integral_constant<int, 0>{});
     };
 
     for (long long tile = tile0; tile < n_tiles; tile += DEPTH * tile_step) {

@@ -45,6 +45,7 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(512, FFT_CHAIN_WAVES_PER_SIMD) tile_fft_ba_ke
 
     const int tid_invariant = FFT_TID;
     const int nthreads = FFT_NTHREADS;
+    const bool nt_load = (pb.nt & FFT_TILE_NT & 1) != 0, nt_store = (pa.nt & FFT_TILE_NT & 2) != 0;  // TileParams::nt
     const int log2L = pb.log2L, log2C = pb.log2C;  // == pa's (the planner checks)
     const int L = 1 << log2L;
     const int log2TPC = log2L - log2E;
@@ -75,7 +76,8 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(512, FFT_CHAIN_WAVES_PER_SIMD) tile_fft_ba_ke
     const int cpr_mask = (1 << log2CPR) - 1;
 
     vec16<T> nxt[H][E];
-    auto prefetch = [&](long long tile) __attribute__((always_inline)) {
+    auto prefetch_as = [&](auto nt_tag, long long tile) __attribute__((always_inline)) {
+        constexpr int NTL = decltype(nt_tag)::value;
         const TileCoord<T> tc = tile_coord(pb, tile);
         int tid = tid_invariant;
         FFT_OPAQUE(tid);
@@ -87,12 +89,16 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(512, FFT_CHAIN_WAVES_PER_SIMD) tile_fft_ba_ke
             const int l0 = (g & cpr_mask) * V;
             const cpx<T>* src = tc.in + (long long)t * pb.in_c + (long long)(l0 >> pb.in_blk_bits) * pb.in_blk_stride + (l0 & ((1 << pb.in_blk_bits) - 1));
             if (live) {
-                nxt[0][i] = *reinterpret_cast<const vec16<T>*>(src);
+                nxt[0][i] = fft_ld16<NTL>(reinterpret_cast<const vec16<T>*>(src));
             } else {
                 FFT_UNROLL
                 for (int vv = 0; vv < V; vv++) nxt[0][i].c[vv] = mk<T>((T)0, (T)0);
             }
         }
+    };
+    auto prefetch = [&](long long tile) __attribute__((always_inline)) {  // one wave-uniform branch per tile, the loads stay one clause
+        if (nt_load) prefetch_as(std::integral_constant<int, 1>{}, tile);
+        else prefetch_as(std::integral_constant<int, 0>{}, tile);
     };
 
     long long tile0 = FFT_BID;
@@ -195,16 +201,21 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(512, FFT_CHAIN_WAVES_PER_SIMD) tile_fft_ba_ke
             }
         }
         cpx<T>* outp = pa.out + tc.b * pa.out_b + col0 * pa.out_c;
-        FFT_UNROLL
-        for (int e = 0; e < E; e++) {
-            const long long K = r + ((long long)e << log2TPC);
-            if ((tc.c0 + V * j) < pb.n_cols) {
-                vec16<T> v;
-                FFT_UNROLL
-                for (int vv = 0; vv < V; vv++) v.c[vv] = x[0][e][vv];
-                *reinterpret_cast<vec16<T>*>(outp + K * pa.out_k + V * j) = v;
+        auto store_as = [&](auto nt_tag) __attribute__((always_inline)) {
+            constexpr int NTS = decltype(nt_tag)::value;
+            FFT_UNROLL
+            for (int e = 0; e < E; e++) {
+                const long long K = r + ((long long)e << log2TPC);
+                if ((tc.c0 + V * j) < pb.n_cols) {
+                    vec16<T> v;
+                    FFT_UNROLL
+                    for (int vv = 0; vv < V; vv++) v.c[vv] = x[0][e][vv];
+                    fft_st16<NTS>(reinterpret_cast<vec16<T>*>(outp + K * pa.out_k + V * j), v);
+                }
             }
-        }
+        };
+        if (nt_store) store_as(std::integral_constant<int, 1>{});
+        else store_as(std::integral_constant<int, 0>{});
     }
 }
 
