@@ -172,7 +172,7 @@ class Pow2Plan {
     std::vector<PassDesc> passes;
     cpx<T>* scratch = nullptr;
     size_t scratch_bytes = 0;
-    cpx<T>* scratch2 = nullptr;  // execute_chain: the inverse transform's image (allocated on first use, scratch_bytes)
+    cpx<T>* scratch2 = nullptr;  // execute_chain: the inverse transform's image (scratch_bytes; allocated in build() for prefer_chain plans)
     std::vector<cpx<T>*> pass_tables;  // one device blob per pass: [sa | sb | t0 | t1 | t2]
     cpx<T>* tw_half = nullptr;  // W_n^k, k < n/2 (RADIX2_GLOBAL)
     TeamDesc<T> team;           // team.ok: execute() runs the team kernel, with the two-pass plan queued behind it as fallback
@@ -722,6 +722,9 @@ class Pow2Plan {
             scratch_bytes = (size_t)chunk * (size_t)per;
             scratch = (cpx<T>*)rt->dmalloc(scratch_bytes);
             if (!scratch) return false;
+            // forward + inverse plans whose middle passes chain: the second image is allocated with the plan, not in the first
+            // execute (a failed allocation only means the unchained path runs: execute_chain tries once more, then reports false)
+            if (prefer_chain && algo_ == ALGO_AUTO && ends_chainable(passes.front(), passes.back())) scratch2 = (cpx<T>*)rt->dmalloc(scratch_bytes);
         }
         if (passes.size() > 1 && algo_ == ALGO_AUTO) {
             build_team(batch);
