@@ -107,3 +107,19 @@ def test_fused_periodogram_emulated(n, dtype, lds):
         psd, info = E.emu_fused("psd", x, lds_budget=lds, no_fusion=no_fusion, fs=48000.0)
         assert psd.shape == (3, n // 2 + 1)
         assert np.linalg.norm(psd - ref) / np.linalg.norm(ref) < TOL[np.dtype(dtype)] * 4
+
+
+@pytest.mark.parametrize("kind", ["xcorr", "circ"])
+def test_chained_pass_over_several_launch_groups(kind, monkeypatch):
+    """Forward-last + inverse-first pass as ONE kernel (fft_kernels_chain.h) with the batch cut into launch groups
+    (FFT_HIP_CHUNK_MB = 1: 16 transforms of m = 4096 fp64 per group, 40 = 16 + 16 + 8): the per-transform spectral table of the
+    cross-correlation must follow the group offset."""
+    monkeypatch.setenv("FFT_HIP_CHUNK_MB", "1")
+    n, batch = (1500, 40) if kind == "xcorr" else (4096, 40)
+    x = lcg((batch, n), n, np.complex128)
+    y = lcg((batch, n), n + 1, np.complex128)
+    h = lcg((n,), n + 2, np.complex128)
+    out, info = E.emu_fused(kind, x, y=y if kind == "xcorr" else None, h=h if kind == "circ" else None, lds_budget=40000)
+    assert info[1] == 2 and info[3] == 16, info  # chained, launch groups of 16
+    ref = O.oracle_xcorr(x, y) if kind == "xcorr" else O.oracle_conv_circular(x, h)
+    assert rel(out, ref) < TOL[np.dtype(np.complex128)] * 4

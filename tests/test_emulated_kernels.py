@@ -309,3 +309,13 @@ def test_team_kernel_even_odd_row_split(n, batch, dtype, log2seats, threads, lds
         y, info = E.emu_fft_team(x, d, log2seats=log2seats, n_xcc=2, threads=threads, lds_budget=lds, inplace=inplace)
         assert info[0] >= 400 and info[6] == 1, "the split column step was not planned"
         assert rel(y, oracle(x, d)) < TEAM_TOL[dtype]
+
+
+def test_bluestein_chained_over_several_launch_groups(monkeypatch):
+    """m = 4096 fp64 = 64 x 64 chained, 40 transforms in launch groups of 16 (FFT_HIP_CHUNK_MB = 1)."""
+    monkeypatch.setenv("FFT_HIP_CHUNK_MB", "1")
+    n, batch = 2000, 40
+    x = O.gen_lcg(n, n, batch).astype(np.complex128)
+    y, info = E.emu_fft(x, -1, lds_budget=40000)
+    assert info[0] == 12 and info[4] == 2 and info[7] == 16, info[:8]
+    assert rel(y, O.oracle_fft(x, -1, "bluestein")) < 1e-12

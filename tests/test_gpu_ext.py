@@ -217,7 +217,8 @@ def test_fused_consumers_batched_vs_oracle(gpu_lib, kind, nx, nh, batch, dtype):
 
 
 @pytest.mark.parametrize("n,batch,dtype", [(1009, 7, np.complex128), (1009, 7, np.complex64), (100003, 3, np.complex128),
-                                           (100003, 3, np.complex64), (1000003, 2, np.complex128), (3000017, 1, np.complex128), (1000, 33, np.complex64)])
+                                           (100003, 3, np.complex64), (30011, 5, np.complex64), (30011, 5, np.complex128),
+                                           (1000003, 2, np.complex128), (3000017, 1, np.complex128), (1000, 33, np.complex64)])
 def test_bluestein_fused_equals_unfused_and_oracle(gpu_lib, n, batch, dtype):
     import fftlib
     x = lcg((batch, n), n, dtype)
@@ -229,9 +230,9 @@ def test_bluestein_fused_equals_unfused_and_oracle(gpu_lib, n, batch, dtype):
             plan.set_option(fftlib.OPT_NO_FUSION, no_fusion)
             plan.set_option(fftlib.OPT_NO_CHAIN, no_chain)
             fused = plan.info().fused
-            # m = 2^18 = 512 x 512, 2^21 = 128^3, 2^23 = 256 x 128 x 256: the planner picks splits whose end tiles agree, those chain;
+            # m = 2^16 = 256 x 256, 2^18 = 512 x 512, 2^21 = 128^3, 2^23 = 256 x 128 x 256: the planner picks splits whose end tiles agree, those chain;
             # m = 2048 is a single pass
-            assert fused == (0 if no_fusion else 1 if (no_chain or n < 100000) else 2), (n, fused)
+            assert fused == (0 if no_fusion else 1 if (no_chain or n < 30000) else 2), (n, fused)
             buf.upload(x)
             plan.execute_ptr(buf.ptr, buf.ptr)  # in place: the user's array is both the first load and the last store
             assert plan.sync() == 0
@@ -335,3 +336,43 @@ def test_planner_pins_the_borrowed_arrays(gpu_lib):
     plan = lib.fft_plan_dft_1d(n, x.ctypes.data, y.ctypes.data, -1, FFT_CONSERVE_MEMORY)
     assert plan and lib.fft_gpu_host_is_registered_hip(x.ctypes.data) == 0
     lib.fft_destroy_plan(plan)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,nx,batch,dtype", [("xcorr", 1 << 17, 11, np.complex64), ("circ", 1 << 18, 7, np.complex128),
+                                                 ("conv", 60000, 9, np.complex64)])
+def test_chained_fused_plans_over_several_launch_groups(gpu_lib, kind, nx, batch, dtype):
+    """The chained middle pass (csrc/fft_kernels_chain.h) with the batch cut into launch groups of 2-4 transforms
+    (chunk_mb policy): per-transform spectral tables (cross-correlation) must follow the group offset; against the oracle
+    and against the same plan with the two kernels."""
+    import fftlib
+    fftlib.set_policy(team=1, min_batch=0, chunk_mb=4)  # m = 2^18 fp32 (2 MiB): groups of 2; 2^18 fp64 (4 MiB): groups of 1; 2^16: 8
+    x = lcg((batch, nx), nx, dtype)
+    y = lcg((batch, nx), nx + 1, dtype) if kind == "xcorr" else None
+    nh = 5000 if kind == "conv" else nx
+    h = lcg((nh,), nh + 9, dtype) if kind in ("conv", "circ") else None
+    plan = fftlib.ExtPlan.fused(kind, nx, batch, h, dtype)
+    info = plan.info()
+    assert info.fused == 2 and info.chunk_batch < batch, (info.fused, info.chunk_batch)
+    bufs = [fftlib.DeviceBuffer(x.nbytes)]
+    bufs[0].upload(x)
+    if y is not None:
+        bufs.append(fftlib.DeviceBuffer(y.nbytes))
+        bufs[1].upload(y)
+    out = fftlib.DeviceBuffer(batch * plan.out_len * np.dtype(dtype).itemsize)
+    res = []
+    for no_chain in (0, 1):
+        plan.set_option(fftlib.OPT_NO_CHAIN, no_chain)
+        plan.execute_fused(bufs[0].ptr, bufs[1].ptr if y is not None else None, out.ptr, 1.0)
+        assert plan.sync() == 0
+        res.append(out.download((batch, plan.out_len), dtype))
+    x64 = x.astype(np.complex128)
+    ref = {"conv": lambda: O.oracle_conv_linear(x64, h.astype(np.complex128)),
+           "circ": lambda: O.oracle_conv_circular(x64, h.astype(np.complex128)),
+           "xcorr": lambda: O.oracle_xcorr(x64, y.astype(np.complex128))}[kind]()
+    r = rel(res[0], ref)
+    assert r <= TOL[np.dtype(dtype)] and r <= TIGHT[np.dtype(dtype)] * 16, (kind, nx, r)
+    assert rel(res[0], res[1].astype(np.complex128)) <= TIGHT[np.dtype(dtype)] * 16
+    plan.destroy()
+    for b in bufs + [out]:
+        b.free()
