@@ -376,3 +376,34 @@ def test_chained_fused_plans_over_several_launch_groups(gpu_lib, kind, nx, batch
     plan.destroy()
     for b in bufs + [out]:
         b.free()
+
+
+@pytest.mark.gpu
+def test_random_sizes_roundtrip_parseval_and_numpy(gpu_lib):
+    """Size-independent properties over a seeded mix of lengths (powers of two of every pass count, Bluestein lengths whose
+    padded transform is single-pass, two-pass chained / unchained, three-pass) and batches: IFFT(FFT(x)) = x, Parseval, and the
+    first transform against numpy's pocketfft in double precision."""
+    import fftlib
+    rng = np.random.default_rng(20260101)
+    sizes = [1 << k for k in (6, 11, 13, 14, 15, 16, 17, 19, 21)] + [int(v) for v in rng.integers(1000, 300000, 14)] + [999983, 1048573, 2 ** 20 + 1]
+    for n in sizes:
+        for dtype in (np.complex64, np.complex128):
+            batch = int(max(1, min(64, (1 << 22) // n)))
+            batch = int(rng.integers(1, batch + 1))
+            x = (rng.standard_normal((batch, n)) + 1j * rng.standard_normal((batch, n))).astype(dtype)
+            a, b = fftlib.DeviceBuffer(x.nbytes), fftlib.DeviceBuffer(x.nbytes)
+            a.upload(x)
+            fwd, inv = fftlib.Plan(n, batch, -1, dtype), fftlib.Plan(n, batch, 1, dtype)
+            fwd.execute_ptr(a.ptr, b.ptr)
+            assert fwd.sync() == 0
+            X = b.download(x.shape, dtype)
+            inv.execute_ptr(b.ptr, b.ptr)
+            assert inv.sync() == 0
+            back = b.download(x.shape, dtype)
+            tol = TOL[np.dtype(dtype)]
+            assert rel(back, x.astype(np.complex128)) < tol, (n, batch, dtype)
+            e_t = np.sum(np.abs(x.astype(np.complex128)) ** 2, axis=1)
+            e_f = np.sum(np.abs(X.astype(np.complex128)) ** 2, axis=1) / n
+            assert np.max(np.abs(e_f - e_t) / e_t) < tol * 4, (n, batch, dtype)
+            assert rel(X[:1], np.fft.fft(x[:1].astype(np.complex128), axis=1)) < tol, (n, batch, dtype)
+            fwd.destroy(); inv.destroy(); a.free(); b.free()
