@@ -89,6 +89,7 @@ struct PassDesc {
     int n_cols = 0;  // valid columns along the tiled dimension; -1: the batch (single-pass row kernel)
     int log2Ntw = 0;
     int nthreads = 0;
+    int tw_o = 0;  // fftk::TileParams::tw_o
     int smem_bytes = 0;
     int seg_bytes = 0;  // contiguous bytes per row segment on the c-contiguous side
 };
@@ -684,30 +685,7 @@ class Pow2Plan {
             }
         }
 
-        // ---- tables: one blob per pass, laid out exactly as the kernel keeps it in LDS
-        for (auto& p : passes) {
-            layout_tables(p);
-            std::vector<cpx<T>> blob((size_t)p.tables_elems), part;
-            for (auto& z : blob) { z.re = (T)1; z.im = (T)0; }
-            const long long L = 1ll << p.log2L;
-            make_twiddle_table<T>(part, L, 1ll << p.sa_bits, 1);
-            std::copy(part.begin(), part.end(), blob.begin());
-            make_twiddle_table<T>(part, L, 1ll << (p.log2L - p.sa_bits), 1ll << p.sa_bits);
-            std::copy(part.begin(), part.end(), blob.begin() + p.o_sb);
-            if (p.twiddle) {
-                const long long Ntw = 1ll << p.log2Ntw;
-                make_twiddle_table<T>(part, Ntw, 1ll << p.t0_bits, 1);
-                std::copy(part.begin(), part.end(), blob.begin() + p.o_t0);
-                make_twiddle_table<T>(part, Ntw, 1ll << p.t1_bits, 1ll << p.t0_bits);
-                std::copy(part.begin(), part.end(), blob.begin() + p.o_t1);
-                make_twiddle_table<T>(part, Ntw, 1ll << p.t2_bits, 1ll << (p.t0_bits + p.t1_bits));
-                std::copy(part.begin(), part.end(), blob.begin() + p.o_t2);
-            }
-            cpx<T>* d = (cpx<T>*)rt->dmalloc(blob.size() * SZ);
-            if (!d) return false;
-            rt->h2d(d, blob.data(), blob.size() * SZ);
-            pass_tables.push_back(d);
-        }
+        if (!make_pass_tables()) return false;
 
         // ---- Infinity-Cache blocking of the batch (multi-pass only)
         chunk = batch;
@@ -742,6 +720,35 @@ class Pow2Plan {
     // four-step engine -- cols-strided sub-transforms of length rows, `cols` of them per matrix, no inter-pass twiddle.
     // Needs rows = 2^log2rows to fit one LDS tile and cols to be a multiple of the 16-byte lane access; false otherwise
     // (the caller then goes through a transpose).  execute(in, out, n_matrices, inverse) transforms whole matrices.
+    // one table blob per pass, laid out exactly as the kernel keeps it in LDS: stage tables [sa | sb], then the two- / three-level
+    // inter-pass twiddle tables of W_(2^log2Ntw) where the pass applies one
+    bool make_pass_tables() {
+        for (auto& p : passes) {
+            layout_tables(p);
+            std::vector<cpx<T>> blob((size_t)p.tables_elems), part;
+            for (auto& z : blob) { z.re = (T)1; z.im = (T)0; }
+            const long long L = 1ll << p.log2L;
+            make_twiddle_table<T>(part, L, 1ll << p.sa_bits, 1);
+            std::copy(part.begin(), part.end(), blob.begin());
+            make_twiddle_table<T>(part, L, 1ll << (p.log2L - p.sa_bits), 1ll << p.sa_bits);
+            std::copy(part.begin(), part.end(), blob.begin() + p.o_sb);
+            if (p.twiddle) {
+                const long long Ntw = 1ll << p.log2Ntw;
+                make_twiddle_table<T>(part, Ntw, 1ll << p.t0_bits, 1);
+                std::copy(part.begin(), part.end(), blob.begin() + p.o_t0);
+                make_twiddle_table<T>(part, Ntw, 1ll << p.t1_bits, 1ll << p.t0_bits);
+                std::copy(part.begin(), part.end(), blob.begin() + p.o_t1);
+                make_twiddle_table<T>(part, Ntw, 1ll << p.t2_bits, 1ll << (p.t0_bits + p.t1_bits));
+                std::copy(part.begin(), part.end(), blob.begin() + p.o_t2);
+            }
+            cpx<T>* d = (cpx<T>*)rt->dmalloc(blob.size() * SZ);
+            if (!d) return false;
+            rt->h2d(d, blob.data(), blob.size() * SZ);
+            pass_tables.push_back(d);
+        }
+        return true;
+    }
+
     bool build_columns(RT* runtime, int log2rows, int cols, int n_matrices) {
         rt = runtime;
         log2n = log2rows;
@@ -760,20 +767,57 @@ class Pow2Plan {
         a.n_ct = (int)((cols + (1ll << a.log2C) - 1) >> a.log2C);
         a.fam = fftk::FAM_R4;
         passes.assign(1, a);
-        PassDesc& p = passes[0];
-        layout_tables(p);
-        std::vector<cpx<T>> blob((size_t)p.tables_elems), part;
-        for (auto& z : blob) { z.re = (T)1; z.im = (T)0; }
-        const long long L = 1ll << p.log2L;
-        make_twiddle_table<T>(part, L, 1ll << p.sa_bits, 1);
-        std::copy(part.begin(), part.end(), blob.begin());
-        make_twiddle_table<T>(part, L, 1ll << (p.log2L - p.sa_bits), 1ll << p.sa_bits);
-        std::copy(part.begin(), part.end(), blob.begin() + p.o_sb);
-        cpx<T>* d = (cpx<T>*)rt->dmalloc(blob.size() * SZ);
-        if (!d) return false;
-        rt->h2d(d, blob.data(), blob.size() * SZ);
-        pass_tables.push_back(d);
+        if (!make_pass_tables()) return false;
         chunk = n_matrices;
+        ok = true;
+        return true;
+    }
+
+    // The same column transforms in TWO passes with wide tiles, for row counts whose single column pass has narrow segments
+    // (rows x C columns must fit one LDS tile: C = 2 at 4096 rows fp32) or does not fit at all: the four-step split
+    // rows = L1 * L2 applied to strided columns.  With r = r1 L2 + r2 and k = k1 + L1 k2:
+    //   pass A  for every r2 (the tile's o index): length-L1 transforms over the rows r1 L2 + r2, times W_rows^(k1 r2) (the twiddle
+    //           index is o, TileParams::tw_o), stored in place of their inputs (row k1 L2 + r2);
+    //   pass B  for every k1 (o): length-L2 transforms over the CONTIGUOUS rows k1 L2 + r2, stored to row k1 + L1 k2.
+    // Both passes move cols-wide contiguous row segments; pass B changes rows, so the pair is never in place: execute() goes
+    // in -> scratch -> out like every two-pass plan (in == out allowed).
+    bool build_columns2(RT* runtime, int log2rows, int cols, int n_matrices) {
+        rt = runtime;
+        log2n = log2rows;
+        max_batch = n_matrices;
+        algo = ALGO_SPLIT_RADIX;
+        if (log2rows < 6 || cols < V || (cols % V) != 0) return false;
+        const int l1 = (log2rows + 1) / 2, l2 = log2rows - l1;
+        const long long per_matrix = (long long)cols << log2rows;
+        long long ext = 1;
+        while (ext < cols) ext <<= 1;
+        PassDesc a, b;
+        a.log2L = l1; a.E = tile_E(1ll << l1, 1); a.loadm = fftk::LOAD_CCONTIG; a.storem = fftk::STORE_CCONTIG;
+        a.twiddle = 1; a.log2Ntw = log2rows; a.tw_o = 1;
+        a.in_b = per_matrix; a.out_b = per_matrix; a.in_c = 1; a.out_c = 1;
+        a.n_o = 1 << l2; a.in_o = cols; a.out_o = cols;
+        a.in_l = (long long)cols << l2; a.out_k = (long long)cols << l2;
+        a.n_cols = cols;
+        if (!choose_tile(a, ext, rt->max_lds_bytes())) return false;
+        a.n_ct = (int)((cols + (1ll << a.log2C) - 1) >> a.log2C);
+        a.fam = fftk::FAM_R4;
+        b.log2L = l2; b.E = tile_E(1ll << l2, 1); b.loadm = fftk::LOAD_CCONTIG; b.storem = fftk::STORE_CCONTIG;
+        b.twiddle = 0; b.log2Ntw = 0;
+        b.in_b = per_matrix; b.out_b = per_matrix; b.in_c = 1; b.out_c = 1;
+        b.n_o = 1 << l1; b.in_o = (long long)cols << l2; b.out_o = cols;
+        b.in_l = cols; b.out_k = (long long)cols << l1;
+        b.n_cols = cols;
+        if (!choose_tile(b, ext, rt->max_lds_bytes())) return false;
+        b.n_ct = (int)((cols + (1ll << b.log2C) - 1) >> b.log2C);
+        b.fam = fftk::FAM_R4;
+        passes.clear();
+        passes.push_back(a);
+        passes.push_back(b);
+        if (!make_pass_tables()) return false;
+        chunk = n_matrices;  // execute() steps through the batch in units of 2^log2n elements: one launch group = every matrix
+        scratch_bytes = (size_t)n_matrices * (size_t)per_matrix * SZ;
+        scratch = (cpx<T>*)rt->dmalloc(scratch_bytes);
+        if (!scratch) return false;
         ok = true;
         return true;
     }
@@ -873,6 +917,7 @@ class Pow2Plan {
         tp.in_blk_bits = p.in_blk_bits; tp.in_blk_stride = p.in_blk_stride;
         tp.inverse = inverse ? 1 : 0;
         tp.scale = scale;
+        tp.tw_o = p.tw_o;
         tp.run_if = run_if;
         static const int ablate = FFT_EXP_ENV("FFT_HIP_ABLATE") ? atoi(FFT_EXP_ENV("FFT_HIP_ABLATE")) : 0;  // profiling only
         tp.ablate = ablate & ~48;

@@ -103,6 +103,8 @@ struct TileParams {
     int tiles_per_b;
     int pair16;   // tile order: pair half-line neighbours on one XCD (see tile_coord)
     int ablate;   // profiling only (FFT_HIP_ABLATE): 1 skip inter-pass twiddle, 2 skip stages
+    int tw_o;     // 1: the inter-pass twiddle's second index is the tile's `o` index, not its column (two-pass COLUMN transforms of
+                  // 2D plans: the columns of the tile are matrix columns, the four-step index n2 is the row offset o)
     int nt;       // non-temporal hint on the pass's HBM streams: bit 0 data loads, bit 1 result stores.  The planner sets a bit
                   // where the side moves whole 128-byte lines (measured: +5 % at n = 64, +13 % on 128^3 fp64; with 64-byte row
                   // segments the hint throws away the half line the neighbouring tile is about to ask for: -6...12 %)
@@ -412,6 +414,7 @@ struct TileCoord {
     long long b;      // transform index (multi-pass tiles; the single-pass kernel's transforms are its columns)
     long long oidx;   // o * out_o: offset of this tile's outputs inside the transform (hooks)
     long long iidx;   // o * in_o
+    int o;            // the tile's o index itself (TileParams::tw_o)
 };
 
 template <typename T>
@@ -441,6 +444,7 @@ FFT_DEVICE TileCoord<T> tile_coord(const TileParams<T>& p, long long tile) {
     tc.b = b;
     tc.oidx = (long long)o * p.out_o;
     tc.iidx = (long long)o * p.in_o;
+    tc.o = (int)o;
     long long boff_in = b * p.in_b, boff_out = b * p.out_b;
     if (FFT_ABLATE(p.ablate & 16)) boff_out %= (8 * p.out_b);  // timing experiment only: scratch side wraps into 8 transforms (cache-resident)
     if (FFT_ABLATE(p.ablate & 32)) boff_in %= (8 * p.in_b);
@@ -599,7 +603,8 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2((E == 4 ? 1024 : 512), (E == 4 ? FFT_WAVES_PE
 
     // x[h][e][v] *= W_Ntw^(row * column): row = r + TPC*e is the index along the transformed axis (frequency K in
     // a column pass, sample l in a row pass), column = the tile column.  Two- or three-level LDS tables.
-    auto interpass_twiddle = [&](cpx<T> (&x)[H][E][V], int c0, int r, int j) __attribute__((always_inline)) {
+    // tw_col >= 0: every column of the tile takes W^(K * tw_col) (TileParams::tw_o); -1: W^(K * column)
+    auto interpass_twiddle = [&](cpx<T> (&x)[H][E][V], int c0, int r, int j, int tw_col) __attribute__((always_inline)) {
         const cpx<T>* t0 = tab + p.o_t0;
         const cpx<T>* t1 = tab + p.o_t1;
         const cpx<T>* t2 = tab + p.o_t2;
@@ -612,7 +617,7 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2((E == 4 ? 1024 : 512), (E == 4 ? FFT_WAVES_PE
                 const unsigned K = (unsigned)(r + (e << log2TPC));
                 FFT_UNROLL
                 for (int vv = 0; vv < V; vv++) {
-                    const unsigned m = K * (unsigned)(c0 + h * CG + V * j + vv);
+                    const unsigned m = K * (tw_col >= 0 ? (unsigned)tw_col : (unsigned)(c0 + h * CG + V * j + vv));
                     cpx<T> w = cmul(t0[m & m0], t1[(m >> p.t0_bits) & m1]);
                     if (p.t2_bits) w = cmul(w, t2[m >> sh2]);
                     x[h][e][vv] = cmul(x[h][e][vv], w);
@@ -698,7 +703,7 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2((E == 4 ? 1024 : 512), (E == 4 ? FFT_WAVES_PE
         // row pass of a multi-pass plan: the inter-pass twiddle W_N^(k1 * n2) is applied HERE, to the loaded samples
         // (n2 = r + TPC*e runs along the row, k1 = the tile column) -- this pass hides arithmetic behind its memory
         // traffic, the column pass before it does not
-        if (TWIDDLE && LOADM == LOAD_LCONTIG && !FFT_ABLATE(p.ablate & 1)) interpass_twiddle(x, tc.c0, r, j);
+        if (TWIDDLE && LOADM == LOAD_LCONTIG && !FFT_ABLATE(p.ablate & 1)) interpass_twiddle(x, tc.c0, r, j, p.tw_o ? tc.o : -1);
 
         if (!FFT_ABLATE(p.ablate & 2)) {
             FFT_SYNC_LDS();  // staging image / previous tile's last exchange fully consumed
@@ -727,7 +732,7 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2((E == 4 ? 1024 : 512), (E == 4 ? FFT_WAVES_PE
 #endif
 
         // ---- inter-pass twiddle (column pass: applied to the results, before the store), scale, inverse swap
-        if (TWIDDLE && LOADM == LOAD_CCONTIG && !FFT_ABLATE(p.ablate & 1)) interpass_twiddle(x, tc.c0, r, j);
+        if (TWIDDLE && LOADM == LOAD_CCONTIG && !FFT_ABLATE(p.ablate & 1)) interpass_twiddle(x, tc.c0, r, j, p.tw_o ? tc.o : -1);
         if (p.inverse) {
             FFT_UNROLL
             for (int h = 0; h < H; h++) {

@@ -49,7 +49,8 @@ static void launch_flat(RT* rt, K kernel, long long total, A... args) {
 // model applications/image_fft.c:35-60).  Row-column decomposition on the batched engine:
 //   rows    = ONE batched 1D execute (n = cols, batch = rows * matrices);
 //   columns = a strided batch: the column pass of the four-step engine in place (rows a power of two that fits one
-//             LDS tile, cols a multiple of the 16-byte lane access), otherwise transpose -> batched 1D -> transpose.
+//             LDS tile with >= 64-byte row segments, cols a multiple of the 16-byte lane access), the same transforms as two
+//             strided passes with wide tiles for more rows, otherwise transpose -> batched 1D -> transpose.
 // The inverse is scaled ONCE by 1 / (rows * cols): each 1D inverse carries its own 1 / length and nothing is applied on
 // top (the reference's image_fft.c:64-71 divides by rows * cols AGAIN after two already scaled 1D inverses).
 // ---------------------------------------------------------------------------
@@ -78,6 +79,19 @@ class Plan2D {
             if ((rows & (rows - 1)) == 0) {
                 colp = new Pow2Plan<T, RT>();
                 if (!colp->build_columns(rt, ilog2(rows), cols, n_matrices)) { delete colp; colp = nullptr; }
+                // many rows: the one-pass column tile (rows x C columns in LDS) gets narrow (C = 2 at 4096 rows fp32: 16-byte row
+                // segments) or does not fit at all -- the four-step split of the column transforms keeps whole lines
+                // (build_columns2; measured profiles/r2_ext_plans.txt)
+                static const int min_seg = FFT_EXP_ENV("FFT_HIP_COL2_MINSEG") ? atoi(FFT_EXP_ENV("FFT_HIP_COL2_MINSEG")) : 64;
+                if (!colp || colp->passes[0].seg_bytes < min_seg) {
+                    Pow2Plan<T, RT>* two = new Pow2Plan<T, RT>();
+                    if (two->build_columns2(rt, ilog2(rows), cols, n_matrices)) {
+                        delete colp;
+                        colp = two;
+                    } else {
+                        delete two;
+                    }
+                }
             }
             if (!colp) {
                 colt = new AnyPlan<T, RT>();

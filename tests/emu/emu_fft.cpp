@@ -178,7 +178,7 @@ static int run2d(const void* in, void* out, int rows, int cols, int nm, int dir,
     if (lds_budget > 0) rt.lds_budget = lds_budget;
     ffteng::Plan2D<T, emu::Runtime> plan;
     if (!plan.build(&rt, rows, cols, dir, nm)) return -1;
-    if (info) info[0] = plan.colp ? 1 : (plan.colt ? 2 : 0);  // 1 direct column pass, 2 transpose path
+    if (info) info[0] = plan.colp ? (plan.colp->passes.size() == 2 ? 3 : 1) : (plan.colt ? 2 : 0);  // 1 direct column pass, 2 transpose path, 3 two strided passes
     plan.execute((const fftk::cpx<T>*)in, (fftk::cpx<T>*)out, nm);
     return 0;
 }

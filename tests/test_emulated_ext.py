@@ -26,7 +26,12 @@ def lcg(shape, seed, dtype):
     (16, 24, 3, np.complex64, 0, 1),      # cols not a power of two (rows: Bluestein over cols), still a multiple of the lane access
     (8, 5, 2, np.complex64, 0, 2),        # odd cols: 16-byte accesses impossible -> transpose path
     (12, 32, 2, np.complex128, 0, 2),     # rows not a power of two -> transpose + Bluestein
-    (256, 8, 1, np.complex64, 1024, 2),   # rows do not fit one LDS tile of this budget -> transpose path
+    (256, 8, 1, np.complex64, 1024, 3),   # rows do not fit one LDS tile of this budget -> two strided passes (16 x 16)
+    (64, 32, 2, np.complex128, 4096, 3),  # the one-pass tile would be narrow (< 64-byte segments) -> two strided passes (8 x 8)
+    (512, 8, 1, np.complex64, 2048, 3),   # 32 x 16: unequal factors, the twiddle index is the row offset
+    (64, 100, 2, np.complex64, 4096, 3),  # column count not a power of two: the last column tile is partly padding
+    (128, 6, 1, np.complex64, 1024, 3),
+    (64, 5, 1, np.complex64, 0, 2),       # odd column count -> transpose path
     (1, 64, 2, np.complex64, 0, 0),       # a single row: rows only
 ])
 def test_fft2d_emulated(rows, cols, nm, dtype, lds, path):

@@ -32,9 +32,12 @@ def lcg(shape, seed, dtype):
 @pytest.mark.parametrize("rows,cols,nm,dtype", [
     (32, 64, 1, np.complex128), (128, 32, 2, np.complex64),
     (1024, 1024, 1, np.complex64),      # direct column pass, 8 MiB image
-    (4096, 256, 1, np.complex64),       # the longest column that fits one LDS tile
-    (2048, 64, 1, np.complex128),
-    (8192, 16, 1, np.complex64),        # columns longer than a tile -> transpose path
+    (4096, 256, 1, np.complex64),       # the longest column that fits one LDS tile: narrow there -> two strided passes (64 x 64)
+    (2048, 64, 2, np.complex128),       # two strided passes, two matrices
+    (8192, 16, 1, np.complex64),        # columns longer than a tile: two strided passes (128 x 64)
+    (4096, 24, 1, np.complex64),        # ... with a column count that is not a power of two (the rows go through Bluestein)
+    (65536, 8, 1, np.complex64),        # 256 x 256 strided
+    (2048, 3, 1, np.complex64),         # odd column count: no 16-byte lane access -> transpose path
     (17, 33, 3, np.complex128),         # nothing is a power of two: Bluestein both ways, odd pitch
     (60, 100, 2, np.complex64),
     (1, 4096, 2, np.complex64), (256, 2, 1, np.complex128), (2, 2, 5, np.complex64),
