@@ -1053,12 +1053,28 @@ class Pow2Plan {
         k.post_tab = h.post_tab ? h.post_tab + tab_off : nullptr;
         k.post_tab_b = h.post_tab_b;
         k.post_mode = (h.post_tab || h.post_mode == HOOK_ABS2) ? h.post_mode : HOOK_NONE;
+        // the full 64 KiB tile of L in {128 ... 1024} gets an instantiation with L and C baked in (as launch_one_h does)
+        const int full_c = 13 - ilog2(SZ / 8) - a.log2L;
+        static const int use_fixed = FFT_EXP_ENV("FFT_HIP_FIXED") ? atoi(FFT_EXP_ENV("FFT_HIP_FIXED")) : 1;
+        if (use_fixed && a.log2C == full_c) {
+            switch (a.log2L) {
+                case 7: launch_chain_kernel(tile_fft_ba_kernel<T, ((7 << 8) | (13 - (SZ == 16 ? 1 : 0) - 7))>, q, a.nthreads); return;
+                case 8: launch_chain_kernel(tile_fft_ba_kernel<T, ((8 << 8) | (13 - (SZ == 16 ? 1 : 0) - 8))>, q, a.nthreads); return;
+                case 9: launch_chain_kernel(tile_fft_ba_kernel<T, ((9 << 8) | (13 - (SZ == 16 ? 1 : 0) - 9))>, q, a.nthreads); return;
+                case 10: launch_chain_kernel(tile_fft_ba_kernel<T, ((10 << 8) | (13 - (SZ == 16 ? 1 : 0) - 10))>, q, a.nthreads); return;
+                default: break;
+            }
+        }
+        launch_chain_kernel(tile_fft_ba_kernel<T, 0>, q, a.nthreads);
+    }
+    template <class K>
+    void launch_chain_kernel(K kernel, const fftk::ChainParams<T>& q, int nthreads) {
         const int smem = chain_smem();
-        int per_cu = rt->max_blocks_per_cu(tile_fft_ba_kernel<T>, a.nthreads, (size_t)smem);
+        int per_cu = rt->max_blocks_per_cu(kernel, nthreads, (size_t)smem);
         if (per_cu < 1) per_cu = 1;
         long long grid = (long long)rt->num_cus() * per_cu;
         if (grid > q.b.n_tiles) grid = q.b.n_tiles;
-        rt->launch(tile_fft_ba_kernel<T>, grid, a.nthreads, (size_t)smem, q);
+        rt->launch(kernel, grid, nthreads, (size_t)smem, q);
     }
     // out = IFFT( post_f( FFT( pre_f(in) ) ) ) with the ends of `hf` (load side + spectral product) and `hi` (store side of
     // the inverse); requires chain_capable().  One HBM round trip less than execute_hooked twice.

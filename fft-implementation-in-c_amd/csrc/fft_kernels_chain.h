@@ -24,15 +24,19 @@ struct ChainParams {
     int off_tables_a;  // LDS byte offset of a's table blob (b's sits at b.off_tables)
 };
 
-// E = 8 elements per thread, 512 threads, FAM_SR16 (radix-8 split-radix codelets) for the row part and FAM_R4 for the
+// E = 8 elements per thread, 512 threads, FAM_SR16 (radix-8 split-radix codelets) for the row part and FFT_CHAIN_FAM_A for the
 // column part -- AUTO's families for these two pass types.
 #ifndef FFT_CHAIN_ORDER
 #define FFT_CHAIN_ORDER 1  // 1: spectral table requested before the row stages, next tile after the product; 0: next tile first, table in line
 #endif
+#ifndef FFT_CHAIN_FAM_A
+#define FFT_CHAIN_FAM_A FAM_SR16  // butterfly family of the column part: radix-8 (one exchange less than AUTO's radix-4 column passes) measured +2...9 % here
+#endif
 #ifndef FFT_CHAIN_WAVES_PER_SIMD
 #define FFT_CHAIN_WAVES_PER_SIMD 2  // measured: 157 VGPRs without spills beat 128 with (tools/ab_chain.py, profiles/r2_ab_chain.txt)
 #endif
-template <typename T>
+// FIXED != 0 bakes (log2L << 8 | log2C) into the instantiation, as in tile_fft_kernel
+template <typename T, int FIXED = 0>
 FFT_KERNEL void FFT_LAUNCH_BOUNDS2(512, FFT_CHAIN_WAVES_PER_SIMD) tile_fft_ba_kernel(ChainParams<T> q) {
     constexpr int E = 8, H = 1;
     constexpr int V = vec16<T>::V;
@@ -46,7 +50,7 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(512, FFT_CHAIN_WAVES_PER_SIMD) tile_fft_ba_ke
     const int tid_invariant = FFT_TID;
     const int nthreads = FFT_NTHREADS;
     const bool nt_load = (pb.nt & FFT_TILE_NT & 1) != 0, nt_store = (pa.nt & FFT_TILE_NT & 2) != 0;  // TileParams::nt
-    const int log2L = pb.log2L, log2C = pb.log2C;  // == pa's (the planner checks)
+    const int log2L = FIXED ? (FIXED >> 8) : pb.log2L, log2C = FIXED ? (FIXED & 255) : pb.log2C;  // == pa's (the planner checks)
     const int L = 1 << log2L;
     const int log2TPC = log2L - log2E;
     const int log2J = log2C - log2V;
@@ -179,7 +183,7 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2(512, FFT_CHAIN_WAVES_PER_SIMD) tile_fft_ba_ke
             for (int vv = 0; vv < V; vv++) x[0][e][vv] = cswap(x[0][e][vv]);
         }
         FFT_SYNC_LDS();  // the row part's last exchange is fully consumed
-        stockham_all_stages<T, E, FAM_R4, V, H>(x, smem, pa.group_bytes, twa, r, j, log2J, log2TPC, log2L, []() {});
+        stockham_all_stages<T, E, FFT_CHAIN_FAM_A, V, H>(x, smem, pa.group_bytes, twa, r, j, log2J, log2TPC, log2L, []() {});
         // the tile's columns in the inverse pass: index of (k1, k2) among the n / L columns = o * out_o + c0
         const long long col0 = tc.oidx + tc.c0;  // b's out_o = L1 = the column count per value of o
         {
