@@ -675,7 +675,10 @@ class Pow2Plan {
         // MI355X per pass shape: rows-in/rows-out and column passes run radix-4 stages, the
         // row pass with transposed store runs radix-8 (split-radix codelet) stages.
         {
-            int auto_fams[3] = {fftk::FAM_R4, fftk::FAM_R4, fftk::FAM_SR16};  // single-pass, column pass, row pass
+            // column passes: radix-8 since the instantiations with L and C baked in exist for it too (profiles/r2_ab_column_family.txt:
+            // fp32 +2...12 % at every multi-pass size, fp64 from 2^18 up; fp64 below: radix-4 stays 2 % ahead)
+            const int col_fam = (SZ == 8 || log2n >= 18) ? fftk::FAM_SR16 : fftk::FAM_R4;
+            int auto_fams[3] = {fftk::FAM_R4, col_fam, fftk::FAM_SR16};  // single-pass, column pass, row pass
             if (const char* e = FFT_EXP_ENV("FFT_HIP_AUTO_FAMS")) sscanf(e, "%d,%d,%d", &auto_fams[0], &auto_fams[1], &auto_fams[2]);
             for (auto& p : passes) {
                 if (algo_ != ALGO_AUTO) p.fam = fam;
@@ -834,7 +837,7 @@ class Pow2Plan {
         // immediate: fewer integer VALU ops and address VGPRs; measured +9 % at N = 2^20).  Shapes: the full
         // 64 KiB tile of L in {128, 256, 512, 1024} in AUTO's families, column pass and transposing row pass.
         constexpr bool HAS_FIX = (E == 8 && H == 1) &&
-                                 ((LM == fftk::LOAD_CCONTIG && FAM == fftk::FAM_R4 && TW) ||
+                                 ((LM == fftk::LOAD_CCONTIG && (FAM == fftk::FAM_R4 || FAM == fftk::FAM_SR16) && TW) ||
                                   (LM == fftk::LOAD_LCONTIG && SM == fftk::STORE_CCONTIG && FAM == fftk::FAM_SR16 && !TW));
         static const int use_fixed = FFT_EXP_ENV("FFT_HIP_FIXED") ? atoi(FFT_EXP_ENV("FFT_HIP_FIXED")) : 1;
         if (HAS_FIX && use_fixed) {
@@ -981,13 +984,15 @@ class Pow2Plan {
         if (p.loadm == LOAD_LCONTIG && p.storem == STORE_LCONTIG && p.E == 4 && p.fam == FAM_R4 && !p.twiddle) return 1;
         if (p.loadm == LOAD_CCONTIG && p.storem == STORE_CCONTIG && p.E == 8 && p.fam == FAM_R4 && p.twiddle) return 2;
         if (p.loadm == LOAD_LCONTIG && p.storem == STORE_CCONTIG && p.E == 8 && p.fam == FAM_SR16 && !p.twiddle) return 3;
+        if (p.loadm == LOAD_CCONTIG && p.storem == STORE_CCONTIG && p.E == 8 && p.fam == FAM_SR16 && p.twiddle) return 4;
         return 0;
     }
     bool hook_capable() const {
         if (!ok || passes.empty() || log2n == 0) return false;
         if (algo == ALGO_RADIX2_GLOBAL || algo == ALGO_RADIX2_SHFL) return false;
         if (passes.size() == 1) return hook_kind(passes[0]) == 1;
-        return hook_kind(passes.front()) == 2 && hook_kind(passes.back()) == 3;
+        const int first = hook_kind(passes.front());
+        return (first == 2 || first == 4) && hook_kind(passes.back()) == 3;
     }
 
     // side: bit 0 this launch carries the load side of `h`, bit 1 the store side
@@ -1020,6 +1025,7 @@ class Pow2Plan {
             case 1: launch_kernel(tile_fft_kernel<T, 4, 1, FAM_R4, LOAD_LCONTIG, STORE_LCONTIG, false, 0, 3>, tp, -1, p); break;
             case 2: launch_kernel(tile_fft_kernel<T, 8, 1, FAM_R4, LOAD_CCONTIG, STORE_CCONTIG, true, 0, 1 | 4>, tp, -1, p); break;
             case 3: launch_kernel(tile_fft_kernel<T, 8, 1, FAM_SR16, LOAD_LCONTIG, STORE_CCONTIG, false, 0, 2>, tp, -1, p); break;
+            case 4: launch_kernel(tile_fft_kernel<T, 8, 1, FAM_SR16, LOAD_CCONTIG, STORE_CCONTIG, true, 0, 1 | 4>, tp, -1, p); break;
             default: break;
         }
     }
