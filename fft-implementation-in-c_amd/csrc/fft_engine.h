@@ -852,6 +852,15 @@ class Pow2Plan {
                 }
             }
         }
+        // ... and the single-pass rows kernel (E = 4, radix-4) for n = 128, 256 fp32 (fft_rows_list.h says why only those)
+        constexpr bool ROWS_FIX = E == 4 && H == 1 && LM == fftk::LOAD_LCONTIG && SM == fftk::STORE_LCONTIG && FAM == fftk::FAM_R4 && !TW && SZ == 8;
+        if (ROWS_FIX && use_fixed && p.log2C == 13 - p.log2L) {
+            switch (p.log2L) {
+                case 7: launch_fixed<E, H, FAM, LM, SM, TW, ROWS_FIX, 7>(tp, grid, p); return;
+                case 8: launch_fixed<E, H, FAM, LM, SM, TW, ROWS_FIX, 8>(tp, grid, p); return;
+                default: break;
+            }
+        }
         launch_kernel(fftk::tile_fft_kernel<T, E, H, FAM, LM, SM, TW, 0>, tp, grid, p);
     }
 
@@ -995,6 +1004,28 @@ class Pow2Plan {
         return (first == 2 || first == 4) && hook_kind(passes.back()) == 3;
     }
 
+    // the hooked column / transposing row pass with L and C baked in for the full 64 KiB tile of L = 128 ... 1024 (as launch_one_h)
+    template <int FAM, int LM, int SM, bool TW, int HOOK>
+    void launch_hooked_fixed(const fftk::TileParams<T>& tp, const PassDesc& p) {
+        using namespace fftk;
+        static const int use_fixed = FFT_EXP_ENV("FFT_HIP_FIXED") ? atoi(FFT_EXP_ENV("FFT_HIP_FIXED")) : 1;
+        constexpr int D = SZ == 16 ? 1 : 0;
+        // (the fp64 store-hooked row pass spills 23...42 VGPRs with its shape baked in: generic there)
+        constexpr bool FIX_OK = !(SZ == 16 && (HOOK & 2));
+        if constexpr (FIX_OK) {
+          if (use_fixed && p.log2C == 13 - D - p.log2L) {
+            switch (p.log2L) {
+                case 7: launch_kernel(tile_fft_kernel<T, 8, 1, FAM, LM, SM, TW, (7 << 8) | (13 - D - 7), HOOK>, tp, -1, p); return;
+                case 8: launch_kernel(tile_fft_kernel<T, 8, 1, FAM, LM, SM, TW, (8 << 8) | (13 - D - 8), HOOK>, tp, -1, p); return;
+                case 9: launch_kernel(tile_fft_kernel<T, 8, 1, FAM, LM, SM, TW, (9 << 8) | (13 - D - 9), HOOK>, tp, -1, p); return;
+                case 10: launch_kernel(tile_fft_kernel<T, 8, 1, FAM, LM, SM, TW, (10 << 8) | (13 - D - 10), HOOK>, tp, -1, p); return;
+                default: break;
+            }
+          }
+        }
+        launch_kernel(tile_fft_kernel<T, 8, 1, FAM, LM, SM, TW, 0, HOOK>, tp, -1, p);
+    }
+
     // side: bit 0 this launch carries the load side of `h`, bit 1 the store side
     void launch_pass_hooked(size_t ipass, const cpx<T>* in, cpx<T>* out, int nb, bool inverse, T scale, const ExecHooks<T>& h, int side,
                             long long tab_off) {
@@ -1024,8 +1055,8 @@ class Pow2Plan {
             // HOOK bits: 1 load side, 2 store side, 4 table values prefetched with the data (fft_kernels.h)
             case 1: launch_kernel(tile_fft_kernel<T, 4, 1, FAM_R4, LOAD_LCONTIG, STORE_LCONTIG, false, 0, 3>, tp, -1, p); break;
             case 2: launch_kernel(tile_fft_kernel<T, 8, 1, FAM_R4, LOAD_CCONTIG, STORE_CCONTIG, true, 0, 1 | 4>, tp, -1, p); break;
-            case 3: launch_kernel(tile_fft_kernel<T, 8, 1, FAM_SR16, LOAD_LCONTIG, STORE_CCONTIG, false, 0, 2>, tp, -1, p); break;
-            case 4: launch_kernel(tile_fft_kernel<T, 8, 1, FAM_SR16, LOAD_CCONTIG, STORE_CCONTIG, true, 0, 1 | 4>, tp, -1, p); break;
+            case 3: launch_hooked_fixed<FAM_SR16, LOAD_LCONTIG, STORE_CCONTIG, false, 2>(tp, p); break;
+            case 4: launch_hooked_fixed<FAM_SR16, LOAD_CCONTIG, STORE_CCONTIG, true, 1 | 4>(tp, p); break;
             default: break;
         }
     }

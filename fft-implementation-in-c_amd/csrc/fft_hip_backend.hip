@@ -30,6 +30,10 @@ namespace fftk {  // instantiated in fft_rows_o2.hip
     extern template __global__ void tile_fft_kernel<T, E, 1, FAM, LOAD_LCONTIG, STORE_LCONTIG, false, 0>(TileParams<T>);
 FFT_ROWS_LIST(FFT_EXTERN)
 #undef FFT_EXTERN
+#define FFT_EXTERN_FIXED(T, LOG2L, LOG2C) \
+    extern template __global__ void tile_fft_kernel<T, 4, 1, FAM_R4, LOAD_LCONTIG, STORE_LCONTIG, false, ((LOG2L) << 8) | (LOG2C)>(TileParams<T>);
+FFT_ROWS_FIXED_LIST(FFT_EXTERN_FIXED)
+#undef FFT_EXTERN_FIXED
 }  // namespace fftk
 
 #include "fft_engine.h"

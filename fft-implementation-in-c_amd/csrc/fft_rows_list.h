@@ -15,3 +15,8 @@
     X(double, 8, FAM_SR16)      \
     X(double, 8, FAM_R4)        \
     X(double, 8, FAM_R2)
+// the same kernel (E = 4, radix-4: AUTO's single-pass choice) with L and C baked in for the full 64 KiB tile, where that measured
+// faster (profiles/r2_ab_rows_fixed.txt: n = 128, 256 fp32 +10...12 %; n >= 512 and every fp64 size LOSE 10...30 % -- the unrolled
+// stage loop no longer fits the 128-VGPR budget of this kernel)
+// X(T, LOG2L, LOG2C)
+#define FFT_ROWS_FIXED_LIST(X) X(float, 7, 6) X(float, 8, 5)

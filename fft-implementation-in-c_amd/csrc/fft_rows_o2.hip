@@ -8,4 +8,8 @@ namespace fftk {
     template __global__ void tile_fft_kernel<T, E, 1, FAM, LOAD_LCONTIG, STORE_LCONTIG, false, 0>(TileParams<T>);
 FFT_ROWS_LIST(FFT_INSTANTIATE)
 #undef FFT_INSTANTIATE
+#define FFT_INSTANTIATE_FIXED(T, LOG2L, LOG2C) \
+    template __global__ void tile_fft_kernel<T, 4, 1, FAM_R4, LOAD_LCONTIG, STORE_LCONTIG, false, ((LOG2L) << 8) | (LOG2C)>(TileParams<T>);
+FFT_ROWS_FIXED_LIST(FFT_INSTANTIATE_FIXED)
+#undef FFT_INSTANTIATE_FIXED
 }  // namespace fftk
