@@ -532,6 +532,7 @@ class Pow2Plan {
     // worth more than the wider row segments of the split the cost model would pick for a single transform
     // (tools/ab_chain.py, profiles/r2_ab_chain.txt).  The bonus is in the cost model's unit (1 = one pass).
     bool prefer_chain = false;
+    bool wants_hooks = false;  // the plan's owner fuses element-wise work into the first load / last store (execute_hooked)
     static bool ends_chainable(const PassDesc& a, const PassDesc& b) {
         return a.log2L == b.log2L && a.log2C == b.log2C && a.E == 8 && b.E == 8 && a.nthreads == b.nthreads && a.nthreads <= 512 &&
                a.log2H == 0 && b.log2H == 0;
@@ -578,6 +579,11 @@ class Pow2Plan {
             PassDesc p;
             p.log2L = log2n;
             p.E = tile_E(n);
+            // from n = 512 up eight elements per thread and radix-8 stages (two exchanges instead of four or five) beat the
+            // 1024-thread radix-4 kernel: fp32 +14...26 % with the shape baked in, fp64 +8...17 % (profiles/r2_ab_rows_fixed.txt).
+            // Plans that fuse element-wise work into their ends keep the E = 4 kernel: that is the hooked instantiation.
+            static const bool e_forced = FFT_EXP_ENV("FFT_HIP_E") != nullptr;
+            if (!e_forced && !wants_hooks && algo_ == ALGO_AUTO && log2n >= 9) p.E = 8;
             p.loadm = fftk::LOAD_LCONTIG;
             p.storem = fftk::STORE_LCONTIG;
             p.in_c = n; p.in_l = 1; p.out_c = n; p.out_k = 1;
@@ -684,7 +690,7 @@ class Pow2Plan {
                 if (algo_ != ALGO_AUTO) p.fam = fam;
                 else if (p.loadm == fftk::LOAD_CCONTIG) p.fam = auto_fams[1];
                 else if (p.storem == fftk::STORE_CCONTIG) p.fam = auto_fams[2];
-                else p.fam = auto_fams[0];
+                else p.fam = (p.E == 8 && !FFT_EXP_ENV("FFT_HIP_AUTO_FAMS")) ? fftk::FAM_SR16 : auto_fams[0];
             }
         }
 
@@ -858,6 +864,17 @@ class Pow2Plan {
             switch (p.log2L) {
                 case 7: launch_fixed<E, H, FAM, LM, SM, TW, ROWS_FIX, 7>(tp, grid, p); return;
                 case 8: launch_fixed<E, H, FAM, LM, SM, TW, ROWS_FIX, 8>(tp, grid, p); return;
+                default: break;
+            }
+        }
+        // ... and its E = 8 radix-8 form, n = 512 ... 4096, fp32
+        constexpr bool ROWS_FIX8 = E == 8 && H == 1 && LM == fftk::LOAD_LCONTIG && SM == fftk::STORE_LCONTIG && FAM == fftk::FAM_SR16 && !TW && SZ == 8;
+        if (ROWS_FIX8 && use_fixed && p.log2C == 13 - p.log2L) {
+            switch (p.log2L) {
+                case 9: launch_fixed<E, H, FAM, LM, SM, TW, ROWS_FIX8, 9>(tp, grid, p); return;
+                case 10: launch_fixed<E, H, FAM, LM, SM, TW, ROWS_FIX8, 10>(tp, grid, p); return;
+                case 11: launch_fixed<E, H, FAM, LM, SM, TW, ROWS_FIX8, 11>(tp, grid, p); return;
+                case 12: launch_fixed<E, H, FAM, LM, SM, TW, ROWS_FIX8, 12>(tp, grid, p); return;
                 default: break;
             }
         }
@@ -1276,6 +1293,7 @@ class BluesteinPlan {
         while (m < 2ll * n - 1) m <<= 1;
         log2m = ilog2(m);
         core.prefer_chain = true;  // forward + inverse of length m back to back
+        core.wants_hooks = true;
         if (!core.build(rt, log2m, algo, batch)) return false;
         std::vector<cpx<T>> c((size_t)n), b((size_t)m);
         const long double pi = 3.141592653589793238462643383279502884L;

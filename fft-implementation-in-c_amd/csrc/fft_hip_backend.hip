@@ -34,6 +34,10 @@ FFT_ROWS_LIST(FFT_EXTERN)
     extern template __global__ void tile_fft_kernel<T, 4, 1, FAM_R4, LOAD_LCONTIG, STORE_LCONTIG, false, ((LOG2L) << 8) | (LOG2C)>(TileParams<T>);
 FFT_ROWS_FIXED_LIST(FFT_EXTERN_FIXED)
 #undef FFT_EXTERN_FIXED
+#define FFT_EXTERN_FIXED8(T, LOG2L, LOG2C) \
+    extern template __global__ void tile_fft_kernel<T, 8, 1, FAM_SR16, LOAD_LCONTIG, STORE_LCONTIG, false, ((LOG2L) << 8) | (LOG2C)>(TileParams<T>);
+FFT_ROWS_FIXED8_LIST(FFT_EXTERN_FIXED8)
+#undef FFT_EXTERN_FIXED8
 }  // namespace fftk
 
 #include "fft_engine.h"

@@ -246,6 +246,7 @@ class FusedPlan {
         if (mm > (1ll << 29)) return false;
         log2m = ilog2(mm);
         core.prefer_chain = kind != FUSED_PSD;  // forward + inverse back to back (the periodogram has no inverse)
+        core.wants_hooks = true;
         if (!core.build(rt, log2m, ALGO_AUTO, batch)) return false;
         work = (cpx<T>*)rt->dmalloc((size_t)batch * (size_t)mm * SZ);
         if (!work) return false;

@@ -20,3 +20,7 @@
 // stage loop no longer fits the 128-VGPR budget of this kernel)
 // X(T, LOG2L, LOG2C)
 #define FFT_ROWS_FIXED_LIST(X) X(float, 7, 6) X(float, 8, 5)
+// E = 8, radix-8 (AUTO's single-pass choice from n = 512 up), L and C baked in: fp32 only (profiles/r2_ab_rows_fixed.txt: fp32 +12...14 %
+// over the generic E = 8 kernel, +14...26 % over E = 4 radix-4; the fp64 ones lose 30 %, generic E = 8 radix-8 is fp64's best).
+// X(T, LOG2L, LOG2C)
+#define FFT_ROWS_FIXED8_LIST(X) X(float, 9, 4) X(float, 10, 3) X(float, 11, 2) X(float, 12, 1)

@@ -12,4 +12,8 @@ FFT_ROWS_LIST(FFT_INSTANTIATE)
     template __global__ void tile_fft_kernel<T, 4, 1, FAM_R4, LOAD_LCONTIG, STORE_LCONTIG, false, ((LOG2L) << 8) | (LOG2C)>(TileParams<T>);
 FFT_ROWS_FIXED_LIST(FFT_INSTANTIATE_FIXED)
 #undef FFT_INSTANTIATE_FIXED
+#define FFT_INSTANTIATE_FIXED8(T, LOG2L, LOG2C) \
+    template __global__ void tile_fft_kernel<T, 8, 1, FAM_SR16, LOAD_LCONTIG, STORE_LCONTIG, false, ((LOG2L) << 8) | (LOG2C)>(TileParams<T>);
+FFT_ROWS_FIXED8_LIST(FFT_INSTANTIATE_FIXED8)
+#undef FFT_INSTANTIATE_FIXED8
 }  // namespace fftk
