@@ -289,13 +289,14 @@ class Pow2Plan {
         rt->h2d(d.tables, blob.data(), blob.size() * SZ);
         // Small executes keep the multi-pass schedule: the launch's fixed costs (team formation, pipeline fill, the last
         // transforms of uneven teams) and an intermediate that still fits the Infinity Cache favour it.  Measured crossover
-        // (tools/batch_crossover.py, profiles/r2_batch_crossover.txt, round-2 kernels): n = 2^20 fp32 from 32 transforms
-        // (256 MiB per execute: 132 vs 118 Gpoint/s; 152 vs 126 at 64), fp64 2^19 from 64 (512 MiB), 2^18 from 256
-        // (512 MiB), 2^16 from 2048 (1 GiB) -> by team size: whole-XCD teams 256 MiB (fp32) / 512 MiB (fp64), teams of
-        // 8..16 CUs 512 MiB, smaller teams 1 GiB; and at least 4 transforms per team.  fft_gpu_plan_measure_hip replaces
-        // the table by a measurement of the plan at hand.
+        // (tools/batch_crossover.py, profiles/r2_batch_crossover.txt, against the multi-pass schedule as it stands at the end
+        // of round 2 -- radix-8 column passes, nt streams, measured splits): fp32 n = 2^20 from 256 MiB per execute (131 vs
+        // 116 Gpoint/s at 32 transforms), 2^19 from 512 MiB, 2^18 from 1 GiB, 2^17 only from 4 GiB (185 vs 182), 2^16 from
+        // 2 GiB (193 vs 187); fp64 2^19 / 2^17 / 2^15 from 512 MiB; and at least 4 transforms per team.
+        // fft_gpu_plan_measure_hip replaces the table by a measurement of the plan at hand.
         {
-            const long long mib = d.log2TS >= 5 ? (SZ == 8 ? 256 : 512) : d.log2TS >= 3 ? 512 : 1024;
+            long long mib = 512;
+            if (SZ == 8) mib = d.log2TS >= 5 ? 256 : d.log2TS == 4 ? 512 : d.log2TS == 3 ? 1024 : d.log2TS == 2 ? 4096 : 2048;
             d.min_batch = mode == 1 ? (int)std::max<long long>(4ll * d.n_teams, (mib << 20) / ((long long)SZ << log2n)) : d.n_teams;
         }
         if (rt->policy.team_min_batch > 0) d.min_batch = rt->policy.team_min_batch;

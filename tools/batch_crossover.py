@@ -13,11 +13,11 @@ import fftlib  # noqa: E402
 
 def main():
     fftlib.init()
-    for log2n, dtype in ((20, np.complex64), (18, np.complex64), (16, np.complex64), (19, np.complex128)):
+    for log2n, dtype in ((20, np.complex64), (19, np.complex64), (18, np.complex64), (17, np.complex64), (16, np.complex64), (19, np.complex128), (17, np.complex128), (15, np.complex128)):
         n = 1 << log2n
         esz = np.dtype(dtype).itemsize
         for batch in (8, 16, 32, 64, 128, 256, 512):
-            b = batch * (1 << (20 - log2n)) if dtype == np.complex64 else batch
+            b = batch * (1 << (20 - log2n)) if dtype == np.complex64 else batch * (1 << (19 - log2n))
             if b * n * esz > (4 << 30):
                 continue
             buf = fftlib.DeviceBuffer(b * n * esz)
