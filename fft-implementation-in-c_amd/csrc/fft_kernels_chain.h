@@ -9,8 +9,9 @@
 // never has to leave the CU: row FFTs (forward, last pass) -> spectral product (TileHooks store side) -> column FFTs
 // (inverse, first pass) -> inter-pass twiddle -> tile-major store.  One HBM round trip of the whole image less per
 // forward / inverse pair: 6 -> 5 passes for a three-pass size, 4 -> 3 for a two-pass one.  Needs both passes to have
-// the same tile (sub-transform length and column count), which AUTO's plans have whenever the first and the last
-// factor of the split are equal (2^21 fp64 = 128 x 128 x 128, 2^20 fp32 = 1024 x 1024, ...).
+// the same tile (sub-transform length and column count): the planner prefers splits whose first and last factor are
+// equal for plans that run forward + inverse back to back (Pow2Plan::prefer_chain: 2^16 = 256 x 256, 2^18 = 512 x 512,
+// 2^20 = 1024 x 1024, 2^21 = 128^3, 2^22 = 128 x 256 x 128, ...).  Measurements: profiles/r2_ab_chain.txt.
 #pragma once
 
 #include "fft_kernels.h"
@@ -24,8 +25,8 @@ struct ChainParams {
     int off_tables_a;  // LDS byte offset of a's table blob (b's sits at b.off_tables)
 };
 
-// E = 8 elements per thread, 512 threads, FAM_SR16 (radix-8 split-radix codelets) for the row part and FFT_CHAIN_FAM_A for the
-// column part -- AUTO's families for these two pass types.
+// E = 8 elements per thread, up to 512 threads, radix-8 split-radix codelets (FAM_SR16) for the row part and FFT_CHAIN_FAM_A
+// for the column part.
 #ifndef FFT_CHAIN_ORDER
 #define FFT_CHAIN_ORDER 1  // 1: spectral table requested before the row stages, next tile after the product; 0: next tile first, table in line
 #endif
