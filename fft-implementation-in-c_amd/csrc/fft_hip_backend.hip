@@ -349,10 +349,24 @@ void plan_io_bytes(const fft_gpu_plan* p, size_t* in_bytes, size_t* out_bytes) {
     }
 }
 
-int plan_enqueue(fft_gpu_plan* p, const void* d_in, void* d_out) {
-    if (!p || !d_in || !d_out) return -1;
+// nb > 0: only the first nb transforms of the plan's batch (1D complex plans; the host-pointer pipeline's last group)
+int plan_enqueue(fft_gpu_plan* p, const void* d_in, void* d_out, int nb = 0) {
+    if (!p || !d_in || !d_out || nb > p->batch) return -1;
     DeviceGuard guard(p->device);
     const bool inv = p->dir > 0;
+    if (nb > 0 && nb < p->batch) {
+        if (p->p32) p->p32->execute((const fftk::cpx<float>*)d_in, (fftk::cpx<float>*)d_out, nb, inv);
+        else if (p->p64) p->p64->execute((const fftk::cpx<double>*)d_in, (fftk::cpx<double>*)d_out, nb, inv);
+        else if (p->b32) p->b32->execute((const fftk::cpx<float>*)d_in, (fftk::cpx<float>*)d_out, nb);
+        else if (p->b64) p->b64->execute((const fftk::cpx<double>*)d_in, (fftk::cpx<double>*)d_out, nb);
+        else return -1;
+        hipError_t e2 = hipGetLastError();
+        if (e2 != hipSuccess) {
+            fprintf(stderr, "fft_hip: kernel launch failed: %s\n", hipGetErrorString(e2));
+            return -1;
+        }
+        return 0;
+    }
     if (p->d32) p->d32->execute((const fftk::cpx<float>*)d_in, (fftk::cpx<float>*)d_out, p->batch);
     else if (p->d64) p->d64->execute((const fftk::cpx<double>*)d_in, (fftk::cpx<double>*)d_out, p->batch);
     else if (p->r32 && p->kind == PLAN_R2C) p->r32->execute_r2c((const float*)d_in, (fftk::cpx<float>*)d_out, p->batch);
@@ -1053,11 +1067,70 @@ int fft_gpu_get_device_hip(void) {
 
 // host-pointer batched transform: one batched plan, 64-bit offsets (the reference loops
 // single transforms with `in + i * n` in int arithmetic, gpu/fft_gpu.c:366-374)
+// Host arrays that are page-locked (fft_malloc / fft_gpu_host_register_hip / hipHostMalloc) go through the device in groups of
+// ~128 MiB on three streams: while group g is transformed, group g + 1 is on its way in and group g - 1 on its way out (PCIe
+// is full duplex), so the call costs about ONE direction's transfer time instead of two plus the transforms.  Pageable arrays
+// cannot be copied asynchronously and take the plain path.  Returns 1 when the pipeline does not apply.
+static int dft_batch_pipelined(const void* in, void* out, int n, int batch, fft_direction dir, fft_precision_t prec) {
+    const size_t esz = prec == FFT_PREC_F32 ? sizeof(complex32_t) : sizeof(complex_t);
+    const size_t per = (size_t)n * esz;
+    if (!fft_gpu_host_is_registered_hip(in) || !fft_gpu_host_is_registered_hip(out)) return 1;
+    long long group = (long long)((128ull << 20) / per);
+    if (group < 1) group = 1;
+    if (group * 3 > batch) return 1;  // fewer than three groups: nothing to overlap
+    fft_gpu_plan_t plan = fft_gpu_plan_1d_ex_hip(n, (int)group, dir, prec, FFT_GPU_ALGO_AUTO);
+    if (!plan) return -1;
+    DeviceGuard guard(plan->device);
+    void* buf[2] = {nullptr, nullptr};
+    hipStream_t s_in = nullptr, s_out = nullptr;
+    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_fft[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
+    int rc = -1;
+    bool ok = hipStreamCreateWithFlags(&s_in, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&s_out, hipStreamNonBlocking) == hipSuccess;
+    for (int k = 0; k < 2 && ok; k++) {
+        buf[k] = plan->rt.dmalloc((size_t)group * per);
+        ok = buf[k] && hipEventCreateWithFlags(&ev_in[k], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&ev_fft[k], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&ev_out[k], hipEventDisableTiming) == hipSuccess;
+    }
+    if (ok) {
+        const char* src = (const char*)in;
+        char* dst = (char*)out;
+        int g = 0;
+        for (long long b0 = 0; b0 < batch && ok; b0 += group, g++) {
+            const int k = g & 1;
+            const int nb = (int)((batch - b0) < group ? (batch - b0) : group);
+            if (g >= 2) ok = hipStreamWaitEvent(s_in, ev_out[k], 0) == hipSuccess;  // the group that used this buffer has left it
+            ok = ok && hipMemcpyAsync(buf[k], src + (size_t)b0 * per, (size_t)nb * per, hipMemcpyHostToDevice, s_in) == hipSuccess &&
+                 hipEventRecord(ev_in[k], s_in) == hipSuccess && hipStreamWaitEvent(plan->rt.stream, ev_in[k], 0) == hipSuccess &&
+                 plan_enqueue(plan, buf[k], buf[k], nb) == 0 && hipEventRecord(ev_fft[k], plan->rt.stream) == hipSuccess &&
+                 hipStreamWaitEvent(s_out, ev_fft[k], 0) == hipSuccess &&
+                 hipMemcpyAsync(dst + (size_t)b0 * per, buf[k], (size_t)nb * per, hipMemcpyDeviceToHost, s_out) == hipSuccess &&
+                 hipEventRecord(ev_out[k], s_out) == hipSuccess;
+        }
+        const bool drained = hipStreamSynchronize(s_in) == hipSuccess && hipStreamSynchronize(s_out) == hipSuccess;
+        if (ok && drained && fft_gpu_plan_sync_hip(plan) == 0) rc = 0;
+    }
+    if (rc != 0) (void)hipGetLastError();
+    for (int k = 0; k < 2; k++) {
+        if (buf[k]) plan->rt.dfree(buf[k]);
+        if (ev_in[k]) (void)hipEventDestroy(ev_in[k]);
+        if (ev_fft[k]) (void)hipEventDestroy(ev_fft[k]);
+        if (ev_out[k]) (void)hipEventDestroy(ev_out[k]);
+    }
+    if (s_in) (void)hipStreamDestroy(s_in);
+    if (s_out) (void)hipStreamDestroy(s_out);
+    fft_gpu_destroy_plan_hip(plan);
+    return rc;
+}
+
 int fft_gpu_dft_1d_batch_hip(const void* in, void* out, int n, int batch, fft_direction dir, fft_precision_t prec) {
     if (!in || !out || n <= 0 || batch <= 0) return -1;
     if (!g_initialized && fft_gpu_init_hip() != 0) return -1;
     const size_t esz = prec == FFT_PREC_F32 ? sizeof(complex32_t) : sizeof(complex_t);
     const size_t bytes = (size_t)n * (size_t)batch * esz;
+    {
+        const int piped = dft_batch_pipelined(in, out, n, batch, dir, prec);
+        if (piped <= 0) return piped;
+    }
     fft_gpu_plan_t plan = fft_gpu_plan_1d_ex_hip(n, batch, dir, prec, FFT_GPU_ALGO_AUTO);
     if (!plan) return -1;
     fft_gpu_memory_t buf = fft_gpu_alloc_bytes_hip(bytes);
