@@ -1069,15 +1069,16 @@ int fft_gpu_get_device_hip(void) {
 // single transforms with `in + i * n` in int arithmetic, gpu/fft_gpu.c:366-374)
 // Host arrays that are page-locked (fft_malloc / fft_gpu_host_register_hip / hipHostMalloc) go through the device in groups of
 // ~128 MiB on three streams: while group g is transformed, group g + 1 is on its way in and group g - 1 on its way out (PCIe
-// is full duplex), so the call costs about ONE direction's transfer time instead of two plus the transforms.  Pageable arrays
-// cannot be copied asynchronously and take the plain path.  Returns 1 when the pipeline does not apply.
+// is full duplex): 36-37 GB/s each way against 26-27 GB/s of the plain copy-all / transform / copy-all path at 2-3 GB.
+// Pageable arrays cannot be copied asynchronously and take the plain path.  Returns 1 when the pipeline does not apply.
 static int dft_batch_pipelined(const void* in, void* out, int n, int batch, fft_direction dir, fft_precision_t prec) {
     const size_t esz = prec == FFT_PREC_F32 ? sizeof(complex32_t) : sizeof(complex_t);
     const size_t per = (size_t)n * esz;
     if (!fft_gpu_host_is_registered_hip(in) || !fft_gpu_host_is_registered_hip(out)) return 1;
     long long group = (long long)((128ull << 20) / per);
     if (group < 1) group = 1;
-    if (group * 3 > batch) return 1;  // fewer than three groups: nothing to overlap
+    // measured (tools/host_batch_time.py): 37 against 27 GB/s each way from 2 GB up, no gain at 0.4 GB (the pipeline's own set-up)
+    if (group * 8 > batch) return 1;  // less than 1 GiB: the plain path
     fft_gpu_plan_t plan = fft_gpu_plan_1d_ex_hip(n, (int)group, dir, prec, FFT_GPU_ALGO_AUTO);
     if (!plan) return -1;
     DeviceGuard guard(plan->device);

