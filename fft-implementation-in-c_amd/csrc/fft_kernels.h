@@ -31,6 +31,10 @@ namespace fftk {
 #ifndef FFT_WAVES_PER_SIMD_E4
 #define FFT_WAVES_PER_SIMD_E4 4
 #endif
+#ifndef FFT_WAVES_PER_SIMD_ROWS8
+#define FFT_WAVES_PER_SIMD_ROWS8 4  // the fp32 E = 8 rows kernel with its shape baked in fits 122 VGPRs (no spills): two workgroups per CU;
+                                    // measured n = 1024 / 2048 / 4096: +5 / +12 / +11 %, n = 512: -6 % (stays at two waves per SIMD)
+#endif
 enum { LOAD_CCONTIG = 0, LOAD_LCONTIG = 1 };
 enum { STORE_CCONTIG = 0, STORE_LCONTIG = 1 };
 enum { FAM_SR16 = 0, FAM_R4 = 1, FAM_R2 = 2 };
@@ -458,8 +462,23 @@ FFT_DEVICE TileCoord<T> tile_coord(const TileParams<T>& p, long long tile) {
 // HOOK: 0 none; bit 0 the load side of TileHooks is compiled in, bit 1 the store side, bit 2 the load-side table values
 // are prefetched together with the data (+ E * 4 VGPRs per group: the 2-waves-per-SIMD kernels; without it they are read
 // when the data is consumed -- the 4-waves-per-SIMD rows kernel, whose 128-VGPR budget has no room for them)
+// waves per SIMD the register budget of an instantiation is sized for.  The fp32 kernels with their shape baked in need only
+// 92-122 VGPRs when built for four waves per SIMD (no spills; built for two they take 150-250 because they may), i.e. two
+// 512-thread workgroups per CU.  Measured (profiles/r2_ab_rows_fixed.txt): the single-pass rows kernel gains 5...12 % from
+// n = 1024 up (n = 512: -6 %); the multi-pass kernels LOSE 9...11 % with two workgroups per CU and keep the two-wave budget.
+#ifndef FFT_WAVES_PER_SIMD_FIX32
+#define FFT_WAVES_PER_SIMD_FIX32 2
+#endif
+template <typename T, int E, int LOADM, int STOREM, int FIXED, int HOOK>
+constexpr int tile_waves_per_simd() {
+    if (E == 4) return FFT_WAVES_PER_SIMD_E4;
+    if (sizeof(T) != 4 || FIXED == 0 || (HOOK & 4)) return FFT_WAVES_PER_SIMD;
+    if (LOADM == LOAD_LCONTIG && STOREM == STORE_LCONTIG) return (FIXED >> 8) >= 10 ? FFT_WAVES_PER_SIMD_ROWS8 : FFT_WAVES_PER_SIMD;  // rows kernel: n = 512 loses 6 %
+    return FFT_WAVES_PER_SIMD_FIX32;
+}
 template <typename T, int E, int H, int FAM, int LOADM, int STOREM, bool TWIDDLE, int FIXED, int HOOK = 0>
-FFT_KERNEL void FFT_LAUNCH_BOUNDS2((E == 4 ? 1024 : 512), (E == 4 ? FFT_WAVES_PER_SIMD_E4 : FFT_WAVES_PER_SIMD)) tile_fft_kernel(TileParams<T> p) {
+FFT_KERNEL void FFT_LAUNCH_BOUNDS2((E == 4 ? 1024 : 512), (tile_waves_per_simd<T, E, LOADM, STOREM, FIXED, HOOK>())) tile_fft_kernel(TileParams<T> p) {
+    constexpr int WAVES = tile_waves_per_simd<T, E, LOADM, STOREM, FIXED, HOOK>();
     constexpr int V = vec16<T>::V;
     constexpr int log2V = Log2<V>::value;
     constexpr int log2E = Log2<E>::value;
@@ -526,7 +545,7 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2((E == 4 ? 1024 : 512), (E == 4 ? FFT_WAVES_PE
         constexpr int NTL = decltype(nt_tag)::value;
         const TileCoord<T> tc = tile_coord(p, tile);
         int r = r_invariant, j = j_invariant, tid = tid_invariant;
-        if (E * H >= 16 || FFT_WAVES_PER_SIMD >= 4 || FFT_FORCE_OPAQUE) {
+        if (E * H >= 16 || (E != 4 && WAVES >= 4) || FFT_FORCE_OPAQUE) {
             FFT_OPAQUE(r);
             FFT_OPAQUE(j);
             FFT_OPAQUE(tid);
@@ -641,7 +660,7 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2((E == 4 ? 1024 : 512), (E == 4 ? FFT_WAVES_PE
         // per-stage LDS address / twiddle index out of the persistent loop and keeps ~100 of them live (spills at
         // 64 + 64 data VGPRs).  At E = 8 the hoisting fits the budget and SAVES the per-tile recomputation (+7 %).
         int r = r_invariant, j = j_invariant, tid = tid_invariant;
-        if (E * H >= 16 || FFT_WAVES_PER_SIMD >= 4 || FFT_FORCE_OPAQUE) {
+        if (E * H >= 16 || (E != 4 && WAVES >= 4) || FFT_FORCE_OPAQUE) {
             FFT_OPAQUE(r);
             FFT_OPAQUE(j);
             FFT_OPAQUE(tid);
