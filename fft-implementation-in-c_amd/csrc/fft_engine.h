@@ -68,6 +68,9 @@ struct ExecHooks {
     int post_mode = fftk::HOOK_NONE;
     long long n_out = 0;       // outputs stored per transform (0: n)
     long long out_pitch = 0;
+    // single-pass plans only (execute_round): the spectral product between the forward and the inverse transform of ONE kernel
+    const fftk::cpx<T>* mid_tab = nullptr;
+    int mid_mode = fftk::HOOK_NONE;
 };
 
 enum Algo { ALGO_AUTO = 0, ALGO_RADIX2 = 1, ALGO_RADIX4 = 2, ALGO_SPLIT_RADIX = 3, ALGO_RADIX2_GLOBAL = 4, ALGO_BLUESTEIN = 5, ALGO_RADIX2_SHFL = 6 };
@@ -1069,14 +1072,32 @@ class Pow2Plan {
             k.out_vec_ok = (pitch % V) == 0 ? 1 : 0;
             if (p.n_cols < 0) tp.out_c = pitch; else tp.out_b = pitch;
         }
+        if (side & 4) {  // FFT -> mid product -> inverse FFT in this one launch (single-pass plans: execute_round)
+            k.mid_tab = h.mid_tab;
+            k.mid_mode = (h.mid_tab || h.mid_mode == HOOK_ABS2) ? h.mid_mode : HOOK_NONE;
+            if (hook_kind(p) == 1) launch_kernel(tile_fft_kernel<T, 4, 1, FAM_R4, LOAD_LCONTIG, STORE_LCONTIG, false, 0, 3 | 8>, tp, -1, p);
+            return;
+        }
         switch (hook_kind(p)) {
-            // HOOK bits: 1 load side, 2 store side, 4 table values prefetched with the data (fft_kernels.h)
+            // HOOK bits: 1 load side, 2 store side, 4 table values prefetched with the data, 8 round trip (fft_kernels.h)
             case 1: launch_kernel(tile_fft_kernel<T, 4, 1, FAM_R4, LOAD_LCONTIG, STORE_LCONTIG, false, 0, 3>, tp, -1, p); break;
             case 2: launch_kernel(tile_fft_kernel<T, 8, 1, FAM_R4, LOAD_CCONTIG, STORE_CCONTIG, true, 0, 1 | 4>, tp, -1, p); break;
             case 3: launch_hooked_fixed<FAM_SR16, LOAD_LCONTIG, STORE_CCONTIG, false, 2>(tp, p); break;
             case 4: launch_hooked_fixed<FAM_SR16, LOAD_CCONTIG, STORE_CCONTIG, true, 1 | 4>(tp, p); break;
             default: break;
         }
+    }
+
+    // ---- single-pass sizes: out = IFFT( mid( FFT( pre(in) ) ) ) * post as ONE kernel (TileHooks::mid_tab): the transform pair
+    // of a small Bluestein or convolution costs one HBM round trip of the user's data, nothing else.  The mid table is shared
+    // by the batch (h.mid_tab) or absent (HOOK_ABS2); per-transform products (cross-correlation) take two kernels.
+    bool round_capable() const { return hook_capable() && passes.size() == 1 && hook_kind(passes[0]) == 1; }
+    void execute_round(const cpx<T>* in, cpx<T>* out, int nb, const ExecHooks<T>& h, T extra_scale = (T)1) {
+        const long long n = 1ll << log2n;
+        const T scale = (T)((1.0L / (long double)n) * (long double)extra_scale);
+        run_if = nullptr;
+        launch_pass_hooked(0, in, out, nb, false, scale, h, 3 | 4, 0);
+        rt->mark(0);
     }
 
     // ---- forward transform -> spectral product -> inverse transform with the forward's LAST pass and the inverse's FIRST
@@ -1335,6 +1356,14 @@ class BluesteinPlan {
             f.post_tab = bfft; f.post_mode = fftk::HOOK_MUL;
             ExecHooks<T> g;
             g.post_tab = chirp; g.post_mode = fftk::HOOK_MUL_CONJ; g.n_out = n; g.out_pitch = n;
+            // m fits one tile: modulate -> FFT -> * FFT(b) -> inverse FFT -> demodulate in ONE kernel
+            if (!no_chain && core.round_capable()) {
+                ExecHooks<T> rr = f;
+                rr.mid_tab = bfft; rr.mid_mode = fftk::HOOK_MUL;
+                rr.post_tab = chirp; rr.post_tab_b = 0; rr.post_mode = fftk::HOOK_MUL_CONJ; rr.n_out = n; rr.out_pitch = n;
+                core.execute_round(in, out, nb, rr, scale);
+                return;
+            }
             // the forward transform's last pass and the inverse's first as one kernel where their tiles agree (m = 2^21 fp64:
             // 128 x 128 x 128): five HBM round trips of the padded image instead of six
             if (!no_chain && core.chain_capable() && core.execute_chain(in, out, nb, f, g, scale)) return;

@@ -1009,18 +1009,19 @@ int fft_gpu_plan_info_hip(fft_gpu_plan_t p, fft_gpu_plan_info_t* info) {
     if (p->b32) {
         fill(&p->b32->core);
         info->bluestein_m = 1 << p->b32->log2m;
-        info->fused = (p->b32->core.hook_capable() && !p->b32->no_fusion) ? ((!p->b32->no_chain && p->b32->core.chain_capable()) ? 2 : 1) : 0;
+        info->fused = (p->b32->core.hook_capable() && !p->b32->no_fusion) ? ((!p->b32->no_chain && p->b32->core.round_capable()) ? 3 : (!p->b32->no_chain && p->b32->core.chain_capable()) ? 2 : 1) : 0;
         info->workspace_bytes += (size_t)p->batch * ((size_t)1 << p->b32->log2m) * sizeof(complex32_t);
     }
     if (p->b64) {
         fill(&p->b64->core);
         info->bluestein_m = 1 << p->b64->log2m;
-        info->fused = (p->b64->core.hook_capable() && !p->b64->no_fusion) ? ((!p->b64->no_chain && p->b64->core.chain_capable()) ? 2 : 1) : 0;
+        info->fused = (p->b64->core.hook_capable() && !p->b64->no_fusion) ? ((!p->b64->no_chain && p->b64->core.round_capable()) ? 3 : (!p->b64->no_chain && p->b64->core.chain_capable()) ? 2 : 1) : 0;
         info->workspace_bytes += (size_t)p->batch * ((size_t)1 << p->b64->log2m) * sizeof(complex_t);
     }
     auto fill_fused = [&](auto* f) {  // fused consumers: the padded transform behind them
         fill(&f->core);
-        info->fused = f->fused() ? ((!f->no_chain && f->kind != ffteng::FUSED_PSD && f->core.chain_capable()) ? 2 : 1) : 0;
+        const bool pair = !f->no_chain && f->kind != ffteng::FUSED_PSD;
+        info->fused = f->fused() ? ((pair && f->kind != ffteng::FUSED_XCORR && f->core.round_capable()) ? 3 : (pair && f->core.chain_capable()) ? 2 : 1) : 0;
     };
     if (p->f32) fill_fused(p->f32);
     if (p->f64) fill_fused(p->f64);

@@ -78,6 +78,12 @@ struct TileHooks {
     int n_out;             // outputs stored per transform
     int pre_mode, post_mode;
     int in_vec_ok, out_vec_ok;  // 16-byte accesses allowed on the user's side (rows 16-byte aligned: even pitch for fp32)
+    // HOOK bit 3 (single-pass kernel only): FFT -> spectral product -> inverse FFT in ONE kernel.  After the forward stages the
+    // spectrum is multiplied by mid_tab[K] (one table for the whole batch; mid_mode as post_mode, HOOK_ABS2 needs none), the
+    // inverse transform runs on the registers (a thread holds the same index set before and after a transform) and the result
+    // goes through the store side above (post_tab / n_out), scaled by TileParams::scale.
+    const cpx<T>* mid_tab;
+    int mid_mode;
 };
 
 template <typename T>
@@ -532,7 +538,7 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2((E == 4 ? 1024 : 512), (tile_waves_per_simd<T
 #endif
     constexpr int DEPTH = FFT_DEPTH;  // 2 = double-buffered prefetch (+32 VGPRs; needs FFT_FORCE_OPAQUE to stay spill-free)
     vec16<T> nxtbuf[DEPTH][H][E];
-    constexpr bool HK_LOAD = (HOOK & 1) != 0, HK_STORE = (HOOK & 2) != 0, HK_TABPF = (HOOK & 4) != 0;
+    constexpr bool HK_LOAD = (HOOK & 1) != 0, HK_STORE = (HOOK & 2) != 0, HK_TABPF = (HOOK & 4) != 0, HK_ROUND = (HOOK & 8) != 0;
     vec16<T> nxttab[HK_TABPF ? DEPTH : 1][HK_TABPF ? H : 1][HK_TABPF ? E : 1];  // the load-side table values of the same chunks
     const bool pre_on = HK_LOAD && p.hk.pre_mode != HOOK_NONE;  // wave-uniform
     // index (inside its transform) of the first sample of lane-load i of group h, and its tile column / row
@@ -752,6 +758,36 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2((E == 4 ? 1024 : 512), (tile_waves_per_simd<T
 
         // ---- inter-pass twiddle (column pass: applied to the results, before the store), scale, inverse swap
         if (TWIDDLE && LOADM == LOAD_CCONTIG && !FFT_ABLATE(p.ablate & 1)) interpass_twiddle(x, tc.c0, r, j, p.tw_o ? tc.o : -1);
+        if (HK_ROUND) {
+            // FFT -> product -> inverse FFT without leaving the CU (TileHooks::mid_tab): slot e holds X[K], K = r + TPC * e, and
+            // that is also the slot layout the stages start from, so the inverse (forward between two re<->im swaps) runs on
+            // the registers as they are
+            FFT_UNROLL
+            for (int h = 0; h < H; h++) {
+                FFT_UNROLL
+                for (int e = 0; e < E; e++) {
+                    const int K = r + (e << log2TPC);
+                    FFT_UNROLL
+                    for (int vv = 0; vv < V; vv++) {
+                        cpx<T> v = x[h][e][vv];
+                        if (p.hk.mid_mode == HOOK_ABS2) v = mk<T>(v.re * v.re + v.im * v.im, (T)0);
+                        else if (p.hk.mid_mode == HOOK_MUL_CONJ) v = cmul_conj(v, p.hk.mid_tab[K]);
+                        else if (p.hk.mid_mode == HOOK_MUL) v = cmul(v, p.hk.mid_tab[K]);
+                        x[h][e][vv] = cswap(v);
+                    }
+                }
+            }
+            FFT_SYNC_LDS();  // the forward transform's last exchange is fully consumed
+            stockham_all_stages<T, E, FAM, V, H>(x, smem, group_bytes, tw, r, j, log2J, log2TPC, log2L, []() {});
+            FFT_UNROLL
+            for (int h = 0; h < H; h++) {
+                FFT_UNROLL
+                for (int e = 0; e < E; e++) {
+                    FFT_UNROLL
+                    for (int vv = 0; vv < V; vv++) x[h][e][vv] = cswap(x[h][e][vv]);
+                }
+            }
+        }
         if (p.inverse) {
             FFT_UNROLL
             for (int h = 0; h < H; h++) {

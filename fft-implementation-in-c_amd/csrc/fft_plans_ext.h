@@ -321,6 +321,14 @@ class FusedPlan {
 
     // forward + spectral product + inverse in one go; the middle of it as ONE kernel where the plan allows (execute_chain)
     void forward_inverse(const cpx<T>* in, int n_in, const cpx<T>* tab, long long tab_b, int post_mode, cpx<T>* out, int n_out, int nb) {
+        if (fused() && !no_chain && core.round_capable() && tab_b == 0) {  // the padded transform fits one tile: ONE kernel
+            ExecHooks<T> rr;
+            rr.n_in = n_in; rr.in_pitch = n_in;
+            rr.mid_tab = tab; rr.mid_mode = post_mode;
+            rr.n_out = n_out; rr.out_pitch = n_out;
+            core.execute_round(in, out, nb, rr);
+            return;
+        }
         if (fused() && !no_chain && core.chain_capable()) {
             ExecHooks<T> f, g;
             f.n_in = n_in; f.in_pitch = n_in;

@@ -87,7 +87,8 @@ typedef struct {
                            described by n_passes/factors is queued behind it as its fallback */
     int fused;          /* Bluestein and fused-consumer plans: 0 the element-wise steps run as kernels of their own, 1 they
                            ride on the first load / last store of the transforms, 2 and the forward transform's last pass and
-                           the inverse's first pass are ONE kernel (2 * n_passes - 1 launches per group of chunk_batch) */
+                           the inverse's first pass are ONE kernel (2 * n_passes - 1 launches per group of chunk_batch), 3 the padded
+                           transform fits one LDS tile and forward transform, product and inverse transform are ONE kernel */
 } fft_gpu_plan_info_t;
 
 /* Per-plan switches (tests and integrators; nothing here changes results) */

@@ -140,6 +140,7 @@ static int run(const void* in, void* out, int n, int batch, int dir, int algo, i
             info[0] = 10 + (int)plan.core.passes.size();
             info[4] = (plan.core.hook_capable() && !plan.no_fusion) ? 1 : 0;  // element-wise steps fused into the FFT passes
             if (info[4] && !plan.no_chain && plan.core.chain_capable()) info[4] = 2;  // ... and forward-last + inverse-first as one kernel
+            if (info[4] && !plan.no_chain && plan.core.round_capable()) info[4] = 3;  // single pass: FFT -> product -> inverse FFT as ONE kernel
             info[7] = plan.core.chunk;
         }
         plan.execute((const C*)in, (C*)out, batch);
@@ -212,6 +213,7 @@ static int run_fused(int kind, const void* x, const void* y, const void* h, int 
     if (info) {
         info[0] = (int)plan.core.passes.size();
         info[1] = plan.fused() ? ((!plan.no_chain && plan.core.chain_capable() && kind != ffteng::FUSED_PSD) ? 2 : 1) : 0;
+        if (plan.fused() && !plan.no_chain && plan.core.round_capable() && kind != ffteng::FUSED_PSD && kind != ffteng::FUSED_XCORR) info[1] = 3;
         info[2] = plan.log2m;
         info[3] = plan.core.chunk;
     }

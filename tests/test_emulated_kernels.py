@@ -120,10 +120,11 @@ def test_bluestein_fused_ends(n, dtype, lds, passes, chained, monkeypatch):
     for d in (-1, 1):
         for inplace in (False, True):
             y, info = E.emu_fft(x, d, lds_budget=lds, inplace=inplace)
-            # info[4]: 1 fused ends, 2 also the forward's last and the inverse's first pass as ONE kernel (fft_kernels_chain.h)
-            assert info[0] == 10 + passes and info[4] == 1 + chained, info[:5]
+            # info[4]: 1 fused ends, 2 also the forward's last and the inverse's first pass as ONE kernel (fft_kernels_chain.h),
+            # 3 single-pass m: modulate -> FFT -> product -> inverse FFT -> demodulate as ONE kernel (TileHooks::mid_tab)
+            assert info[0] == 10 + passes and info[4] == (3 if passes == 1 else 1 + chained), info[:5]
             assert rel(y, O.oracle_fft(x.astype(np.complex128), d, "bluestein")) < tol, (n, d, inplace)
-    if chained:
+    if chained or passes == 1:
         monkeypatch.setenv("FFT_EMU_NO_CHAIN", "1")
         y1, info = E.emu_fft(x, -1, lds_budget=lds)
         assert info[4] == 1
