@@ -93,6 +93,7 @@ struct PassDesc {
     int log2Ntw = 0;
     int nthreads = 0;
     int tw_o = 0;  // fftk::TileParams::tw_o
+    long long col_stride = 1;  // fftk::TileParams::col_stride
     int smem_bytes = 0;
     int seg_bytes = 0;  // contiguous bytes per row segment on the c-contiguous side
 };
@@ -592,6 +593,16 @@ class Pow2Plan {
             p.storem = fftk::STORE_LCONTIG;
             p.in_c = n; p.in_l = 1; p.out_c = n; p.out_k = 1;
             p.n_cols = -1;
+            // fp64, n >= 2048: no LDS staging.  One complex128 is one 16-byte access, so the eight elements l = r + (n/8) e a
+            // thread owns can be loaded and stored directly; the lanes of one row cover 512-byte (n = 2048) / 1 KiB (4096) runs,
+            // the "columns" of the tile are whole transforms n apart (TileParams::col_stride).  Measured (profiles/r2_ab_rows_fixed.txt):
+            // n = 2048: 130 -> 148, 4096: 125 -> 145 Gpoint/s; n = 1024 (256-byte runs): 132 -> 118, stays staged
+            static const int direct64 = FFT_EXP_ENV("FFT_HIP_DIRECT64") ? atoi(FFT_EXP_ENV("FFT_HIP_DIRECT64")) : 1;
+            if (direct64 && SZ == 16 && p.E == 8 && log2n >= 11) {
+                p.loadm = fftk::LOAD_CCONTIG;
+                p.storem = fftk::STORE_CCONTIG;
+                p.col_stride = n;
+            }
             long long ext = 1;
             while (ext < batch) ext <<= 1;
             if (ext < V) ext = V;
@@ -692,6 +703,7 @@ class Pow2Plan {
             if (const char* e = FFT_EXP_ENV("FFT_HIP_AUTO_FAMS")) sscanf(e, "%d,%d,%d", &auto_fams[0], &auto_fams[1], &auto_fams[2]);
             for (auto& p : passes) {
                 if (algo_ != ALGO_AUTO) p.fam = fam;
+                else if (passes.size() == 1 && p.E == 8 && !FFT_EXP_ENV("FFT_HIP_AUTO_FAMS")) p.fam = fftk::FAM_SR16;  // single pass, E = 8 (with or without staging)
                 else if (p.loadm == fftk::LOAD_CCONTIG) p.fam = auto_fams[1];
                 else if (p.storem == fftk::STORE_CCONTIG) p.fam = auto_fams[2];
                 else p.fam = (p.E == 8 && !FFT_EXP_ENV("FFT_HIP_AUTO_FAMS")) ? fftk::FAM_SR16 : auto_fams[0];
@@ -951,6 +963,7 @@ class Pow2Plan {
         tp.inverse = inverse ? 1 : 0;
         tp.scale = scale;
         tp.tw_o = p.tw_o;
+        tp.col_stride = p.col_stride;
         tp.run_if = run_if;
         static const int ablate = FFT_EXP_ENV("FFT_HIP_ABLATE") ? atoi(FFT_EXP_ENV("FFT_HIP_ABLATE")) : 0;  // profiling only
         tp.ablate = ablate & ~48;

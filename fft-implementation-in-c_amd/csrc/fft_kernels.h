@@ -113,6 +113,8 @@ struct TileParams {
     int tiles_per_b;
     int pair16;   // tile order: pair half-line neighbours on one XCD (see tile_coord)
     int ablate;   // profiling only (FFT_HIP_ABLATE): 1 skip inter-pass twiddle, 2 skip stages
+    long long col_stride;  // fp64 (one column per 16-byte access) only: elements between adjacent columns of a tile on the c-contiguous
+                           // sides, 1 everywhere except the staging-free single-pass plan whose "columns" are whole transforms (= n)
     int tw_o;     // 1: the inter-pass twiddle's second index is the tile's `o` index, not its column (two-pass COLUMN transforms of
                   // 2D plans: the columns of the tile are matrix columns, the four-step index n2 is the row offset o)
     int nt;       // non-temporal hint on the pass's HBM streams: bit 0 data loads, bit 1 result stores.  The planner sets a bit
@@ -565,7 +567,7 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2((E == 4 ? 1024 : 512), (tile_waves_per_simd<T
                 if (LOADM == LOAD_CCONTIG) {
                     const long long l = r + ((long long)i << log2TPC);
                     live = (tc.c0 + h * CG + V * j) < p.n_cols;
-                    src = tc.in + l * p.in_l + h * CG + V * j;
+                    src = tc.in + l * p.in_l + (V == 1 ? (long long)(h * CG + j) * p.col_stride : (long long)(h * CG + V * j));
                 } else {
                     const int g = tid + i * nthreads;
                     const int t = h * CG + (g >> log2CPR);
@@ -830,7 +832,7 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS2((E == 4 ? 1024 : 512), (tile_waves_per_simd<T
                             vec16<T> v;
                             FFT_UNROLL
                             for (int vv = 0; vv < V; vv++) v.c[vv] = x[h][e][vv];
-                            cpx<T>* dst = tc.out + K * p.out_k + h * CG + V * j;
+                            cpx<T>* dst = tc.out + K * p.out_k + (V == 1 ? (long long)(h * CG + j) * p.col_stride : (long long)(h * CG + V * j));
                             if (HK_STORE) {
                                 const long long idx0 = tc.oidx + K * p.out_k + tc.c0 + h * CG + V * j;
                                 if (idx0 < p.hk.n_out) {

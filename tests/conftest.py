@@ -23,6 +23,12 @@ def _ensure_product_lib():
 
 def pytest_sessionstart(session):
     _ensure_product_lib()
+    # the CPU emulation of the kernels (tests/emu): built ONCE here, before any multi-process test has its ranks ask for it
+    # (GPU-only sessions do not need it and skip the g++ run)
+    if "gpu" not in (session.config.getoption("-m") or "") or "not gpu" in (session.config.getoption("-m") or ""):
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import emu_lib
+        emu_lib.lib()
 
 
 @pytest.fixture(scope="session")

@@ -25,8 +25,16 @@ def lib():
     if _lib is None:
         so = os.environ.get("FFT_EMU_SO", os.path.join(EMU_DIR, "libfft_emu.so"))  # FFT_EMU_SO: a sanitizer build
         if "FFT_EMU_SO" not in os.environ and _needs_build(so):
-            subprocess.run(["g++", "-O1", "-std=c++17", "-DFFT_EMU", "-DFFT_EXPERIMENTS", "-fPIC", "-shared", "-pthread", "-I" + CSRC,
-                            os.path.join(EMU_DIR, "emu_fft.cpp"), "-o", so], check=True)
+            # several processes may get here at once (the ranks of a gloo test): one builds, under a lock, into a temporary
+            # file that is renamed into place; the others wait for the lock and find the library fresh
+            import fcntl
+            with open(so + ".lock", "w") as lock:
+                fcntl.flock(lock, fcntl.LOCK_EX)
+                if _needs_build(so):
+                    tmp = "%s.%d.tmp" % (so, os.getpid())
+                    subprocess.run(["g++", "-O1", "-std=c++17", "-DFFT_EMU", "-DFFT_EXPERIMENTS", "-fPIC", "-shared", "-pthread", "-I" + CSRC,
+                                    os.path.join(EMU_DIR, "emu_fft.cpp"), "-o", tmp], check=True)
+                    os.replace(tmp, so)
         _lib = C.CDLL(so)
         _lib.emu_fft.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.POINTER(C.c_int)]
