@@ -320,3 +320,15 @@ def test_bluestein_chained_over_several_launch_groups(monkeypatch):
     y, info = E.emu_fft(x, -1, lds_budget=40000)
     assert info[0] == 12 and info[4] == 2 and info[7] == 16, info[:8]
     assert rel(y, O.oracle_fft(x, -1, "bluestein")) < 1e-12
+
+
+@pytest.mark.parametrize("n,batch", [(2048, 3), (4096, 2), (4096, 5)])
+def test_fp64_single_pass_without_staging_emulated(n, batch):
+    """fp64 n >= 2048: the single-pass plan loads and stores its eight elements per thread directly (no LDS staging; the tile's
+    columns are whole transforms, TileParams::col_stride = n), batch not a multiple of the tile's column count, in place too."""
+    x = O.gen_lcg(n, n + 1, batch).astype(np.complex128)
+    for d in (-1, 1):
+        for inplace in (False, True):
+            y, info = E.emu_fft(x, d, lds_budget=160 * 1024, inplace=inplace)
+            assert info[0] == 1 and info[1] == int(np.log2(n)), info[:4]
+            assert rel(y, O.oracle_fft(x, d, "exact")) < 1e-14, (n, d, inplace)
