@@ -198,6 +198,8 @@ class Pow2Plan {
         if (scratch) rt->dfree(scratch);
         if (scratch2) rt->dfree(scratch2);
         scratch2 = nullptr;
+        delete mirror;
+        mirror = nullptr;
         if (team.tables) rt->dfree(team.tables);
         if (team.scratch) rt->dfree(team.scratch);
         if (team.sticky) rt->dfree(team.sticky);
@@ -537,6 +539,12 @@ class Pow2Plan {
     // worth more than the wider row segments of the split the cost model would pick for a single transform
     // (tools/ab_chain.py, profiles/r2_ab_chain.txt).  The bonus is in the cost model's unit (1 = one pass).
     bool prefer_chain = false;
+    // Two-pass plans with unequal factors (odd powers of two): the INVERSE of a forward / inverse pair runs on the mirrored split
+    // L2 x L1, whose first pass has the tile of this plan's last pass -- so the pair chains too (execute_chain).  `mirror` is a
+    // plan of its own (tables only: no scratch, no team kernel) built with the split forced.
+    Pow2Plan* mirror = nullptr;
+    int force_l1 = 0;        // > 0: two-pass split with this log2 L1 only (the mirror plan)
+    bool tables_only = false;  // no scratch image, no team kernel (the mirror plan: its passes run on the owner's images)
     bool wants_hooks = false;  // the plan's owner fuses element-wise work into the first load / last store (execute_hooked)
     static bool ends_chainable(const PassDesc& a, const PassDesc& b) {
         return a.log2L == b.log2L && a.log2C == b.log2C && a.E == 8 && b.E == 8 && a.nthreads == b.nthreads && a.nthreads <= 512 &&
@@ -578,6 +586,7 @@ class Pow2Plan {
         int n_force = 0;
         if (const char* e = FFT_EXP_ENV("FFT_HIP_FORCE_SPLIT")) n_force = sscanf(e, "%d,%d,%d", &force[0], &force[1], &force[2]);
         if (n_force > 0 && force[0] + force[1] + force[2] != log2n) n_force = 0;
+        if (force_l1 > 0 && force_l1 < log2n) { n_force = 2; force[0] = force_l1; force[1] = log2n - force_l1; force[2] = 0; }
 
         // ---- candidate: single pass (rows in, rows out)
         if (n_force <= 1) {
@@ -723,13 +732,27 @@ class Pow2Plan {
             if (c > batch) c = batch;
             chunk = (int)c;
             scratch_bytes = (size_t)chunk * (size_t)per;
-            scratch = (cpx<T>*)rt->dmalloc(scratch_bytes);
-            if (!scratch) return false;
+            if (!tables_only) {
+                scratch = (cpx<T>*)rt->dmalloc(scratch_bytes);
+                if (!scratch) return false;
+            }
             // forward + inverse plans whose middle passes chain: the second image is allocated with the plan, not in the first
             // execute (a failed allocation only means the unchained path runs: execute_chain tries once more, then reports false)
-            if (prefer_chain && algo_ == ALGO_AUTO && ends_chainable(passes.front(), passes.back())) scratch2 = (cpx<T>*)rt->dmalloc(scratch_bytes);
+            if (prefer_chain && algo_ == ALGO_AUTO && passes.size() == 2 && !ends_chainable(passes.front(), passes.back()) &&
+                passes[0].log2L != passes[1].log2L && !tables_only) {
+                mirror = new Pow2Plan<T, RT>();
+                mirror->force_l1 = passes[1].log2L;
+                mirror->tables_only = true;
+                mirror->wants_hooks = true;
+                if (!mirror->build(rt, log2n, ALGO_AUTO, batch) || mirror->passes.size() != 2 || mirror->chunk != chunk ||
+                    !ends_chainable(mirror->passes.front(), passes.back())) {
+                    delete mirror;
+                    mirror = nullptr;
+                }
+            }
+            if (prefer_chain && algo_ == ALGO_AUTO && !tables_only && (mirror || ends_chainable(passes.front(), passes.back()))) scratch2 = (cpx<T>*)rt->dmalloc(scratch_bytes);
         }
-        if (passes.size() > 1 && algo_ == ALGO_AUTO) {
+        if (passes.size() > 1 && algo_ == ALGO_AUTO && !tables_only) {
             build_team(batch);
             if (team.ok && !team_geometry_is_built()) {
                 rt->dfree(team.tables); rt->dfree(team.scratch); rt->dfree(team.sticky);
@@ -1115,8 +1138,10 @@ class Pow2Plan {
 
     // ---- forward transform -> spectral product -> inverse transform with the forward's LAST pass and the inverse's FIRST
     // pass as one kernel (fft_kernels_chain.h): possible when both have the same tile
+    const Pow2Plan* inv_plan() const { return mirror ? mirror : this; }  // whose passes run the inverse half of execute_chain
+    Pow2Plan* inv_plan() { return mirror ? mirror : this; }
     int chain_smem() const {
-        const PassDesc &a = passes.front(), &b = passes.back();
+        const PassDesc &a = inv_plan()->passes.front(), &b = passes.back();
         const int data = (std::max(a.group_bytes, b.group_bytes) + 15) & ~15;
         return data + (a.tables_elems + b.tables_elems) * SZ + 16;
     }
@@ -1124,16 +1149,17 @@ class Pow2Plan {
     int chain_min_log2n = kChainMinLog2n;
     bool chain_capable() const {
         if (!hook_capable() || passes.size() < 2 || log2n < chain_min_log2n) return false;
-        const PassDesc &a = passes.front(), &b = passes.back();
+        if (mirror && !mirror->hook_capable()) return false;
+        const PassDesc &a = inv_plan()->passes.front(), &b = passes.back();
         return a.log2L == b.log2L && a.log2C == b.log2C && a.nthreads == b.nthreads && a.nthreads <= 512 && a.log2H == 0 && b.log2H == 0 && chain_smem() <= rt->max_lds_bytes();
     }
     void launch_chain(const cpx<T>* in, cpx<T>* out, int nb, const ExecHooks<T>& h, long long tab_off) {
         using namespace fftk;
         const size_t last = passes.size() - 1;
-        const PassDesc &a = passes.front(), &b = passes.back();
+        const PassDesc &a = inv_plan()->passes.front(), &b = passes.back();
         ChainParams<T> q;
         q.b = pass_params(last, in, nullptr, nb, false, (T)1);
-        q.a = pass_params(0, nullptr, out, nb, true, (T)1);
+        q.a = inv_plan()->pass_params(0, nullptr, out, nb, true, (T)1);
         const int data = (std::max(a.group_bytes, b.group_bytes) + 15) & ~15;
         q.b.off_tables = data;
         q.off_tables_a = data + b.tables_elems * SZ;
@@ -1185,7 +1211,8 @@ class Pow2Plan {
             launch_chain(scratch, scratch2, cb, hf, (long long)b0 * hf.post_tab_b);
             rt->mark(1);
             if (passes.size() == 3) launch_pass(1, scratch2, scratch2, cb, true, (T)1);
-            launch_pass_hooked(last, scratch2, out + (size_t)b0 * (size_t)op, cb, true, scale, hi, 2, (long long)b0 * hi.post_tab_b);
+            inv_plan()->run_if = nullptr;
+            inv_plan()->launch_pass_hooked(last, scratch2, out + (size_t)b0 * (size_t)op, cb, true, scale, hi, 2, (long long)b0 * hi.post_tab_b);
             rt->mark(2);
         }
         return true;

@@ -72,7 +72,9 @@ def test_fused_linear_convolution_emulated(nx, nh, dtype, lds):
         y, info = E.emu_fused("conv", x, h=h, lds_budget=lds, no_fusion=no_fusion)
         # info[1]: 1 fused ends, 2 also forward-last + inverse-first pass as one kernel (the last two cases: 64 x 64, 16 x 16 x 16)
         # ... 3: the padded transform is a single pass: FFT -> product -> inverse FFT as ONE kernel (TileHooks::mid_tab)
-        assert info[1] == (0 if (no_fusion or info[2] == 0) else (2 if nx >= 1500 else 3 if info[0] == 1 else 1)), info
+        # (two-pass plans with unequal factors chain through the mirrored split where the tiles agree: 1 or 2 there)
+        want = (0,) if (no_fusion or info[2] == 0) else (2,) if nx >= 1500 else (3,) if info[0] == 1 else (1, 2)
+        assert info[1] in want, info
         assert rel(y, ref) < TOL[np.dtype(dtype)] * 4, (nx, nh, no_fusion)
     # and against the defining sum (reference direct_convolution, convolution.c:19-31)
     direct = np.stack([np.convolve(r, h.astype(np.complex128)) for r in x.astype(np.complex128)])

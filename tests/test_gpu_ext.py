@@ -235,7 +235,7 @@ def test_bluestein_fused_equals_unfused_and_oracle(gpu_lib, n, batch, dtype):
             fused = plan.info().fused
             # m = 2^16 = 256 x 256, 2^18 = 512 x 512, 2^21 = 128^3, 2^23 = 256 x 128 x 256: the planner picks splits whose end tiles agree, those chain;
             # m = 2048 is a single pass
-            assert fused == (0 if no_fusion else 1 if no_chain else 3 if n < 3000 else 2), (n, fused)  # 3: m fits one tile, ONE kernel
+            assert fused == (0 if no_fusion else 1 if no_chain else 3 if n < 3000 else 2), (n, fused)  # 3: m fits one tile, ONE kernel; 2: every other m here chains (equal ends, or the mirrored split)
             buf.upload(x)
             plan.execute_ptr(buf.ptr, buf.ptr)  # in place: the user's array is both the first load and the last store
             assert plan.sync() == 0

@@ -29,7 +29,7 @@ def main():
     fftlib.init()
     print("bluestein: n batch dtype | chained ms (Gpt/s) | two kernels ms (Gpt/s)")
     for n, batch, dt in ((1000003, 64, np.complex128), (1000003, 64, np.complex64), (100003, 512, np.complex128), (100003, 512, np.complex64),
-                         (10007, 4096, np.complex64), (30011, 2048, np.complex64), (30011, 1024, np.complex128), (250007, 256, np.complex64),
+                         (10007, 4096, np.complex64), (10007, 2048, np.complex128), (50021, 1024, np.complex64), (50021, 512, np.complex128), (30011, 2048, np.complex64), (30011, 1024, np.complex128), (250007, 256, np.complex64),
                          (1500007, 32, np.complex128), (1500007, 32, np.complex64), (3000017, 16, np.complex128), (6000011, 8, np.complex128)):
         x = (np.random.default_rng(1).standard_normal((batch, n)) + 0j).astype(dt)
         buf = fftlib.DeviceBuffer(x.nbytes); buf.upload(x)
@@ -43,7 +43,7 @@ def main():
     print("fused: kind nx batch dtype | chained ms | two kernels ms")
     for kind, nx, nh, batch, dt in (("conv", 1 << 19, 1000, 64, np.complex64), ("circ", 1 << 20, 0, 64, np.complex64), ("circ", 1 << 21, 0, 32, np.complex128),
                                     ("autocorr", 1 << 20, 0, 32, np.complex128), ("circ", 1 << 16, 0, 1024, np.complex64), ("circ", 1 << 16, 0, 512, np.complex128), ("circ", 1 << 18, 0, 256, np.complex64),
-                                    ("circ", 1 << 18, 0, 128, np.complex128), ("circ", 1 << 22, 0, 16, np.complex64), ("circ", 1 << 17, 0, 512, np.complex64),
+                                    ("circ", 1 << 18, 0, 128, np.complex128), ("circ", 1 << 22, 0, 16, np.complex64), ("circ", 1 << 17, 0, 512, np.complex64), ("circ", 1 << 19, 0, 128, np.complex64), ("circ", 1 << 15, 0, 2048, np.complex128),
                                     ("circ", 1 << 14, 0, 4096, np.complex64), ("circ", 4096, 0, 16384, np.complex64)):
         rng = np.random.default_rng(2)
         x = (rng.standard_normal((batch, nx)) + 0j).astype(dt)
