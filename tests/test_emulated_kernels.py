@@ -334,3 +334,17 @@ def test_fp64_single_pass_without_staging_emulated(n, batch):
             y, info = E.emu_fft(x, d, lds_budget=160 * 1024, inplace=inplace)
             assert info[0] == 1 and info[1] == int(np.log2(n)), info[:4]
             assert rel(y, O.oracle_fft(x, d, "exact")) < 1e-14, (n, d, inplace)
+
+
+@pytest.mark.parametrize("n,dtype,lds", [(1009, np.complex128, 4096), (1009, np.complex64, 4096), (3000, np.complex64, 12000)])
+def test_bluestein_chained_through_the_mirrored_split(n, dtype, lds, monkeypatch):
+    """m = 2^11 / 2^13 in two passes with UNEQUAL factors: the inverse transform runs on the mirrored split (Pow2Plan::mirror),
+    whose first pass shares the forward transform's last tile, so the pair still chains; several launch groups."""
+    monkeypatch.setenv("FFT_HIP_CHUNK_MB", "1")
+    batch = 70
+    x = O.gen_lcg(n, n + 3, batch).astype(dtype)
+    tol = 1e-12 if dtype == np.complex128 else 2e-5
+    for d in (-1, 1):
+        y, info = E.emu_fft(x, d, lds_budget=lds)
+        assert info[0] == 12 and info[4] == 2 and info[7] < batch, info[:8]
+        assert rel(y, O.oracle_fft(x.astype(np.complex128), d, "bluestein")) < tol, (n, d)
