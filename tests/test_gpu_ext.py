@@ -343,7 +343,8 @@ def test_planner_pins_the_borrowed_arrays(gpu_lib):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind,nx,batch,dtype", [("xcorr", 1 << 17, 11, np.complex64), ("circ", 1 << 18, 7, np.complex128),
-                                                 ("conv", 60000, 9, np.complex64)])
+                                                 ("conv", 60000, 9, np.complex64),
+                                                 ("circ", 1 << 17, 9, np.complex64), ("xcorr", 1 << 18, 5, np.complex128)])  # odd powers: mirrored split
 def test_chained_fused_plans_over_several_launch_groups(gpu_lib, kind, nx, batch, dtype):
     """The chained middle pass (csrc/fft_kernels_chain.h) with the batch cut into launch groups of 2-4 transforms
     (chunk_mb policy): per-transform spectral tables (cross-correlation) must follow the group offset; against the oracle
