@@ -95,6 +95,9 @@ inline V16 fft_ld16(const V16* p) { return *p; }
 template <int NT, class V16>
 inline void fft_st16(V16* p, const V16& v) { *p = v; }
 #define FFT_WAIT_VM_LE(n) __atomic_thread_fence(__ATOMIC_SEQ_CST)
+// the lanes of a wave run in lock step on the device: LDS writes that follow LDS reads in program order can never overtake
+// another lane's reads.  The emulation's "lanes" are free-running host threads: a workgroup barrier stands in.
+#define FFT_WAVE_LOCKSTEP() emu::sync_threads()
 #else
 #include <hip/hip_runtime.h>
 #define FFT_KERNEL __global__
@@ -248,6 +251,7 @@ __device__ __forceinline__ void fft_store16_sc1(V16* ptr, const V16& v) {
     asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(ptr), "v"(raw) : "memory");
 }
 #define FFT_WAIT_VM_LE(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")  // at most n of my memory operations still in flight
+#define FFT_WAVE_LOCKSTEP() ((void)0)
 template <int SC1>
 __device__ __forceinline__ void fft_dma16(const void* gsrc, unsigned lane_lds_addr) {
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -42,6 +42,11 @@
 #include "fft_kernels_chain.h"
 #include "fft_team_list.h"
 #include "fft_team_defer.h"
+#if defined(FFT_EMU)
+#include "fft_team_quad.h"
+#else
+#include "fft_team_quad_decl.h"
+#endif
 
 namespace ffteng {
 
@@ -149,6 +154,7 @@ struct TeamDesc {
     bool alll2 = false;   // team_defer_kernel ALLL2 (with NODEFER): every phase handed over during the column step, two arrivals
     bool nodefer = false; // team_defer_kernel NODEFER (with PAIR): no deferred phase, two live windows per team
     bool pair = false;    // team_defer_kernel PAIR: adjacent row tiles in phases (0,1) / (2,3), 2 CB-row result segments (fp32)
+    bool quad = false;    // team_quad_kernel (fft_team_quad.h): whole-line segments, both steps decimated by 4, exchange in four rounds
     int E = 0;  // elements per thread = stage radix (fp32: 16 -> 512 threads, 8 -> 1024 threads; fp64: 8)
     int data_bytes = 0, tables_elems = 0, smem_bytes = 0;
     int o_sb1 = 0, o_sa2 = 0, o_sb2 = 0, o_t0 = 0, o_t1 = 0, sa1_bits = 0, sa2_bits = 0, t0_bits = 0;
@@ -206,6 +212,74 @@ class Pow2Plan {
         team = TeamDesc<T>();
         tw_half = nullptr;
         scratch = nullptr;
+    }
+
+    // ---- team_quad_kernel (fft_team_quad.h): n = L x L with L = 4 E^2, teams of TS = n / (4 tiles) seats.  Built for fp32
+    // n = 2^20 on the device (E = 16, a whole XCD per transform) and for n = 2^12 in the emulation (E = 4, 64-thread
+    // workgroups, teams of 4).  Tables [W_n^x, x < L | W_L^y, y < L]; window: 2 slots of TS images per team.
+    static constexpr int quad_E(int log2n_) { return log2n_ == 20 ? 16 : log2n_ == 12 ? 4 : 0; }
+    void build_team_quad(int batch) {
+        const int mode = rt->policy.team_mode;
+        if (mode <= 0 || SZ != 8 || (log2n & 1)) return;
+        const int E = quad_E(log2n);
+        if (!E || !rt->team_quad(SZ, log2n)) return;
+        TeamDesc<T> d;
+        if (!rt->team_geometry(d.log2seats, d.n_xcc, d.nthreads)) return;
+        const int log2L = log2n / 2;
+        const long long L = 1ll << log2L;
+        if (L != 4ll * E * E) return;
+        const int log2TE = ilog2(d.nthreads) + ilog2(E);  // values of a chunk image
+        d.log2TS = log2n - 2 - log2TE;
+        if (d.log2TS < 2 || d.log2TS > d.log2seats) return;
+        if ((L >> d.log2TS) * E != d.nthreads || (L >> d.log2TS) < 16) return;
+#if !defined(FFT_EMU)
+        if (!(log2n == 20 && d.log2TS == 5)) return;  // the device instantiation
+#else
+        if (!(log2n == 12 && d.log2TS == 2)) return;  // the emulation's instantiation
+#endif
+        if (mode == 1 && !rt->team_default_on(SZ, log2n)) return;
+        d.quad = true;
+        d.E = E;
+        d.NT = 4;
+        d.log2L1 = d.log2L2 = log2L;
+        d.n_teams = d.n_xcc << (d.log2seats - d.log2TS);
+        if (d.n_teams > fftk::TEAM_CTL_MAX_TEAMS) return;
+        d.data_bytes = 2 * (SZ << log2TE);
+        d.tables_elems = (int)(2 * L);
+        d.smem_bytes = d.data_bytes + d.tables_elems * SZ + 16;
+        if (d.smem_bytes > rt->max_lds_bytes()) return;
+        std::vector<cpx<T>> blob, part;
+        make_twiddle_table<T>(blob, L * L, L, 1);
+        make_twiddle_table<T>(part, L, L, 1);
+        blob.insert(blob.end(), part.begin(), part.end());
+        d.scratch_bytes = ((size_t)SZ << (log2TE + d.log2TS)) * 2 * (size_t)d.n_teams;
+        d.tables = (cpx<T>*)rt->dmalloc(blob.size() * SZ);
+        d.scratch = (unsigned char*)rt->dmalloc(d.scratch_bytes);
+        d.sticky = (unsigned*)rt->dmalloc((fftk::TEAM_STICKY_WORDS + fftk::TEAM_CTL_WORDS) * sizeof(unsigned));
+        d.ctl = d.sticky ? d.sticky + fftk::TEAM_STICKY_WORDS : nullptr;
+        if (!d.tables || !d.scratch || !d.sticky) {
+            rt->dfree(d.tables); rt->dfree(d.scratch); rt->dfree(d.sticky);
+            return;
+        }
+        rt->memset_async(d.sticky, 0, fftk::TEAM_STICKY_WORDS * sizeof(unsigned));
+        rt->h2d(d.tables, blob.data(), blob.size() * SZ);
+        d.min_batch = mode == 1 ? (int)std::max<long long>(4ll * d.n_teams, (256ll << 20) / ((long long)SZ << log2n)) : d.n_teams;
+        if (rt->policy.team_min_batch > 0) d.min_batch = rt->policy.team_min_batch;
+        (void)batch;
+        d.ok = true;
+        team = d;
+    }
+
+    void launch_team_quad(const fftk::TeamParams<T>& tp) {
+        const long long grid = (long long)team.n_xcc << team.log2seats;
+        if constexpr (SZ == 8) {
+#if defined(FFT_EMU)
+            rt->launch_coresident(fftk::team_quad_kernel<T, 4, 6, 2>, grid, team.nthreads, (size_t)team.smem_bytes, tp);
+#else
+            rt->launch_coresident(fftk::team_quad_kernel<T, 16, 10, 5>, grid, team.nthreads, (size_t)team.smem_bytes, tp);
+#endif
+        }
+        (void)grid;
     }
 
     // ---- team kernel: geometry, tables, the L2-resident transposition windows, the control block
@@ -365,6 +439,7 @@ class Pow2Plan {
     }
 
     bool team_geometry_is_built() const {
+        if (team.quad) return true;  // build_team_quad only plans the instantiated shapes
 #if defined(FFT_EMU)
         return true;
 #else
@@ -407,7 +482,7 @@ class Pow2Plan {
         // With paired row tiles (PAIR) a result store instruction writes whole 128-byte lines, so the result stream can be
         // non-temporal too (as 64-byte halves it could not: the halves left the L2 one by one, WRITE 8.6 -> 10 GB): +3-5 %
         static const int nt_mask = FFT_EXP_ENV("FFT_HIP_TEAM_NT") ? atoi(FFT_EXP_ENV("FFT_HIP_TEAM_NT")) : -1;
-        tp.nt_mask = nt_mask >= 0 ? nt_mask : (team.nodefer ? 7 : team.pair ? 3 : 1);
+        tp.nt_mask = nt_mask >= 0 ? nt_mask : (team.quad ? 3 : team.nodefer ? 7 : team.pair ? 3 : 1);
         static const int tune = FFT_EXP_ENV("FFT_HIP_TEAM_TUNE") ? atoi(FFT_EXP_ENV("FFT_HIP_TEAM_TUNE")) : 0;
         tp.tune = tune;
         tp.force_no_teams = team_force_fallback ? 1 : 0;  // test hook (fft_gpu_plan_set_option_hip): exercise the fallback on a healthy device
@@ -415,6 +490,10 @@ class Pow2Plan {
         tp.trace_events = team.trace_events;
         tp.scale = scale;
         rt->memset_async(team.ctl, 0, fftk::TEAM_CTL_WORDS * sizeof(unsigned));
+        if (team.quad) {
+            launch_team_quad(tp);
+            return;
+        }
 #if defined(FFT_EMU)
         switch (team.NT) {
             case 1: launch_team_emu<1>(tp); break;
@@ -753,7 +832,8 @@ class Pow2Plan {
             if (prefer_chain && algo_ == ALGO_AUTO && !tables_only && (mirror || ends_chainable(passes.front(), passes.back()))) scratch2 = (cpx<T>*)rt->dmalloc(scratch_bytes);
         }
         if (passes.size() > 1 && algo_ == ALGO_AUTO && !tables_only) {
-            build_team(batch);
+            build_team_quad(batch);
+            if (!team.ok) build_team(batch);
             if (team.ok && !team_geometry_is_built()) {
                 rt->dfree(team.tables); rt->dfree(team.scratch); rt->dfree(team.sticky);
                 team = TeamDesc<T>();

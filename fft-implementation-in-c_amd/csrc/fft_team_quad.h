@@ -1,0 +1,391 @@
+// fft_team_quad.h -- team_quad_kernel: a whole transform per team of CUs of one XCD, ONE HBM round trip, every HBM
+// access a whole 128-byte line (256-byte row segments at n = 2^20), the exchange between the two steps in L2.
+//
+// team_fft_kernel / team_defer_kernel (fft_team.h, fft_team_defer.h) cut a transform n = L x L into 64 KiB tiles of
+// L rows x 8 columns: 64-byte row segments, which a CU's memory pipeline streams at two thirds of the rate of whole
+// lines (profiles/r1e_membench4), three Stockham stages with two LDS exchanges per tile, and five team-wide arrivals
+// per transform with the column step's results handed over tile by tile.  Here a seat (workgroup, one per CU) owns
+// NC = L / TS ADJACENT columns in the column step and NC adjacent rows in the row step (n = 2^20, TS = 32: 32 x 8 bytes =
+// 256-byte segments), i.e. 256 KiB of the transform -- more than LDS holds, so both steps are decimated in time by 4
+// (the four-step split of optimizations/parallel_fft.c:213-272 with each length-L transform itself split 4 x L/4):
+//
+//   column step, chunk a = 0..3: rows j1 = 4 b + a (b < M = L/4) of my NC columns land in LDS (LDS-DMA, 64 KiB, the next
+//       chunk flies meanwhile); length-M transforms as two radix-E stages (M = E^2, ONE LDS exchange, run in place);
+//       the results x W_L^(a kb) wait in registers (4 x E values per thread);
+//   combine: radix-4 butterflies over a, thread-local, then the inter-step twiddle W_n^(k1 j2): the thread now holds
+//       X[k1][j2] for 4 E rows k1 of ONE column j2;
+//   exchange + row step, round r = 0..3: every seat writes a quarter of its values into the team's window in the
+//       XCD's L2 (2 slots x 2 MiB, rewritten every other round: dirty lines are overwritten in L2, not evicted), one
+//       team-wide arrival, every seat pulls its 64 KiB image of the round -- the samples j2 = 4 b' + a' of ONE residue
+//       class a' of its NC rows -- into LDS (sc1 LDS-DMA), runs the length-M transforms and keeps the results;
+//   final: radix-4 over the classes, thread-local; all 4 E results of a thread go out as whole 256-byte row segments.
+//
+// Which class a seat receives in round r rotates with the seat (a' = r - s' / (TS/4) mod 4) and which quarter of its rows
+// a sending wave serves rotates with the wave's own class: both rotations are absorbed by twiddle exponents (a circular
+// shift of a DFT's inputs / outputs is a modulation of its outputs / inputs), so every register index is a compile-time
+// constant and no code is specialised per wave.  Four arrivals per transform (fft_team.h has five), all in the
+// exchange; HBM traffic per transform: n in, n out.
+#pragma once
+
+#include "fft_team_quad_decl.h"
+
+namespace fftk {
+
+template <int E, int LOG2L, int LOG2TS>
+struct QuadShape {
+    static constexpr int L = 1 << LOG2L, TS = 1 << LOG2TS, M = L / 4;
+    static constexpr int LOG2NC = LOG2L - LOG2TS, NC = 1 << LOG2NC;
+    static constexpr int NTHR = NC * E;
+    static constexpr unsigned IMG = (unsigned)NTHR * E * 8u;  // bytes of one chunk image (fp32)
+    static_assert(M == E * E, "the length-L/4 transforms are two radix-E stages");
+    static_assert(NC >= 16 && TS >= 4, "four classes of at least four columns; a quarter of the seats per row block");
+};
+
+// rotation of the column step's exchange image: the value of (row R, column c) sits at position (c + quad_phi(R / E)) mod NC
+// of its row.  Stage 1 writes a row with lanes along c (a rotated row is still one contiguous run of banks), stage 2 reads
+// with lanes along g = R / E (E rows, a bank row apart) and four columns: the rotation spreads the E rows over all banks
+// (NC = 32, E = 16: lanes (g, il) -> position 4 il + (g & 3) + 8 (g >> 2) + const: 32 distinct 8-byte slots per half wave).
+FFT_DEVICE int quad_phi(int g) { return (g & 3) + 8 * (g >> 2); }
+
+// w[e] = base * step^e, e < E: E - 1 products at most log2 E deep
+template <typename T, int E>
+FFT_DEVICE void quad_powers(cpx<T> (&w)[E], cpx<T> base, cpx<T> sp) {
+    w[0] = base;
+    FFT_UNROLL
+    for (int bit = 1; bit < E; bit <<= 1) {
+        FFT_UNROLL
+        for (int e = 0; e < bit; e++) w[e | bit] = cmul(w[e], sp);
+        sp = cmul(sp, sp);
+    }
+}
+
+// Stage 1 of a length-M = E^2 transform of column `col` of the image (rows of W = 2^LOG2W values): thread r takes rows
+// r + E e, radix-E butterfly, twiddle W_M^(r k) = W_L^(4 r k) by powers of one table value, results written IN PLACE
+// (rows r + E k: the rows it has just read; ROT: at the rotated position, read by lanes of the same wave only).
+template <typename T, int E, int LOG2W, int LOG2L, bool ROT>
+FFT_DEVICE void quad_stage1(cpx<T>* img, const cpx<T>* wl, int col, int r, bool swap_in) {
+    constexpr int W = 1 << LOG2W, L = 1 << LOG2L;
+    cpx<T> x[E];
+    FFT_UNROLL
+    for (int e = 0; e < E; e++) x[e] = img[((r + E * e) << LOG2W) + col];
+    if (swap_in) {
+        FFT_UNROLL
+        for (int e = 0; e < E; e++) x[e] = cswap(x[e]);
+    }
+    dft_inplace<T, E>(x);
+    cpx<T> pw[E];
+    pw[1] = wl[(4 * r) & (L - 1)];
+    FFT_UNROLL
+    for (int k = 2; k < E; k++) {
+        const int hb = 1 << (31 - __builtin_clz((unsigned)k));
+        pw[k] = (k == hb) ? cmul(pw[k >> 1], pw[k >> 1]) : cmul(pw[hb], pw[k - hb]);
+    }
+    FFT_UNROLL
+    for (int k = 1; k < E; k++) x[k] = cmul(x[k], pw[k]);
+    if (ROT) FFT_WAVE_LOCKSTEP();  // the rotated positions were read by other lanes of this wave
+    FFT_UNROLL
+    for (int k = 0; k < E; k++) img[((r + E * k) << LOG2W) + (ROT ? ((col + quad_phi(k)) & (W - 1)) : col)] = x[k];
+}
+
+// Stage 2: thread g of column `col` takes the E values of rows r + E g (written by stage 1's threads r), radix-E butterfly:
+// v[k] = Y[g + E k].  `pos` = the column's position in those rows (rotated or not).
+template <typename T, int E, int LOG2W>
+FFT_DEVICE void quad_stage2(cpx<T> (&v)[E], const cpx<T>* img, int pos, int g) {
+    FFT_UNROLL
+    for (int r = 0; r < E; r++) v[r] = img[((r + E * g) << LOG2W) + pos];
+    dft_inplace<T, E>(v);
+}
+
+template <typename T, int E, int LOG2L, int LOG2TS>
+FFT_KERNEL void FFT_QUAD_BOUNDS(E, LOG2L, LOG2TS) team_quad_kernel(TeamParams<T> p) {
+    static_assert(vec16<T>::V == 2, "fp32: a 16-byte access holds the values of two adjacent rows");
+    using S = QuadShape<E, LOG2L, LOG2TS>;
+    constexpr int L = S::L, TS = S::TS, M = S::M, NC = S::NC, LOG2NC = S::LOG2NC, NTHR = S::NTHR;
+    constexpr int log2E = Log2<E>::value;
+    constexpr int NCH = E / 2;   // 16-byte pieces of a chunk image per thread
+    constexpr int PPR = NC / 2;  // 16-byte pieces per image row
+    constexpr int SZ = 8;
+    constexpr unsigned IMG = S::IMG;
+    constexpr size_t SLOT = (size_t)TS * IMG;  // one window slot: every seat's image of one round
+    constexpr long long n = (long long)L * L;
+    FFT_DYN_SMEM(smem);
+
+    const int tid0 = FFT_TID;
+    const int tid = tid0;
+    unsigned char* const img_b[2] = {smem, smem + IMG};
+    unsigned char* const tab_bytes = smem + 2 * (size_t)IMG;
+    const unsigned img_lds0 = FFT_LDS_ADDR(smem);
+    {
+        const vec16<T>* src = reinterpret_cast<const vec16<T>*>(p.tables);
+        vec16<T>* dst = reinterpret_cast<vec16<T>*>(tab_bytes);
+        for (int i = tid; i < (p.tables_bytes >> 4); i += NTHR) dst[i] = src[i];
+    }
+    const cpx<T>* const t0 = reinterpret_cast<const cpx<T>*>(tab_bytes);  // W_n^x, x < L
+    const cpx<T>* const wl = t0 + L;                                       // W_L^y, y < L (also W_n^(L y))
+    unsigned* const sh = reinterpret_cast<unsigned*>(tab_bytes + p.tables_bytes);  // [slot, xcc, ok, timed out]
+
+    // ---- team formation (team_form, fft_team.h)
+    if (tid == 0) team_form(p, sh);
+    FFT_SYNC();
+    FFT_LDS_FRESH();
+    if (!sh[2]) return;
+    const unsigned seat = (FFT_UNIFORM(sh[0]) + (unsigned)p.seat_rot) & ((1u << p.log2seats) - 1u);
+    const int s = (int)(seat & (unsigned)(TS - 1));  // my seat in the team
+    const int team = (int)((FFT_UNIFORM(sh[1]) << (p.log2seats - LOG2TS)) + (seat >> LOG2TS));
+    const int n_teams = p.n_xcc << (p.log2seats - LOG2TS);
+    const int NTR = team < p.nb ? (p.nb - team + n_teams - 1) / n_teams : 0;  // transforms of this team
+    if (NTR == 0) return;
+    if (FFT_TEST_DROP()) return;  // emulation only: a member that never arrives
+
+    unsigned char* const sbase = p.scratch + (size_t)team * 2 * SLOT;
+    unsigned* const flags = p.ctl + TEAM_CTL_FLAGS + 32 * team;
+
+    int n_ev = 0;
+    auto ev = [&]() __attribute__((always_inline)) {
+        if (p.trace && tid == 0 && n_ev < p.trace_events - 1) {
+            p.trace[(long long)FFT_BID * p.trace_events + n_ev] = FFT_CLOCK();
+            n_ev++;
+        }
+    };
+    ev();
+    if (p.trace && tid == 0 && p.trace_events > 1) p.trace[(long long)FFT_BID * p.trace_events + p.trace_events - 1] = (team << 8) | s;
+
+    // everybody has made arrival number g <=> the team's counter >= TS * g (nobody makes arrival g + 1 before everybody has
+    // made g).  Polled by the first wave with scalar loads, the others wait at the workgroup barrier (fft_team.h).
+    auto wait_all = [&](int g) __attribute__((always_inline)) {
+        FFT_LDS_FRESH();
+        if (sh[3]) return;
+        if (tid < FFT_TEAM_POLL_LANES) {
+            const long long tstart = FFT_CLOCK();
+            while ((int)(FFT_L2_COUNT_POLL(flags) - ((unsigned)g << LOG2TS)) < 0) {
+                if (FFT_CLOCK() - tstart > p.timeout_ticks) {
+                    team_report_timeout(p);
+                    sh[3] = 1;
+                    break;
+                }
+                FFT_SLEEP();
+            }
+        }
+        FFT_SYNC_LDS();
+    };
+    auto arrive = [&]() __attribute__((always_inline)) {  // call behind a workgroup barrier, every wave's stores complete
+        if (tid == 0) FFT_L2_COUNT_ADD(flags);
+    };
+
+    // ---- thread coordinates.  Every phase derives them afresh from an opaque copy of the thread id (FFT_OPAQUE): left to
+    // itself the optimizer hoists every LDS address, DMA source and window pointer of every phase out of the transform
+    // loop -- all of them are loop-invariant -- and keeps hundreds of registers live across it.
+    // natural map (stage 1 of both steps, stage 2 and stores of the row step): lanes along the image row
+    //   ncol = t & (NC - 1), nr = t >> LOG2NC
+    // column-step stage 2 / sender map: a wave = E values of g x 4 columns of ONE class ap = j2 mod 4
+    //   g = t & (E - 1), il = (t >> log2E) & 3, wq = t >> (log2E + 2): ap = wq & 3, cc = il + 4 (wq >> 2), c2 = ap + 4 cc
+    const int ap = FFT_UNIFORM((tid >> (log2E + 2)) & 3);
+    const int sigma = s >> (LOG2TS - 2);          // my block of rows: k1 in [M sigma, M sigma + M)
+    auto wn = [&](unsigned x) __attribute__((always_inline)) { return cmul(t0[x & (L - 1)], wl[(x >> LOG2L) & (L - 1)]); };  // W_n^x
+
+    auto in_of = [&](int it) __attribute__((always_inline)) { return p.in + (long long)(team + (long long)it * n_teams) * n; };
+    auto out_of = [&](int it) __attribute__((always_inline)) { return p.out + (long long)(team + (long long)it * n_teams) * n; };
+
+    // LDS-DMA of column chunk a (rows 4 b + a of my NC columns) into image `im`: lane-linear 16-byte pieces, piece
+    // sigma = i NTHR + tid is image row sigma / PPR, columns 2 (sigma mod PPR) ..
+    auto dma_chunk = [&](const cpx<T>* inb, int a, int im) __attribute__((always_inline)) {
+        int tid = tid0;
+        FFT_OPAQUE(tid);
+        const cpx<T>* src = inb + ((long long)(4 * (tid / PPR) + a) << LOG2L) + NC * s + 2 * (tid % PPR);
+        constexpr long long step = (long long)(4 * (NTHR / PPR)) << LOG2L;
+        const unsigned lds = img_lds0 + (unsigned)im * IMG;
+        if (p.nt_mask & 1) {
+            FFT_UNROLL
+            for (int i = 0; i < NCH; i++) FFT_DMA16_NT(src + i * step, img_b[im], lds, (unsigned)(i * NTHR + tid) * 16u);
+        } else {
+            FFT_UNROLL
+            for (int i = 0; i < NCH; i++) FFT_DMA16(src + i * step, img_b[im], lds, (unsigned)(i * NTHR + tid) * 16u);
+        }
+    };
+    // LDS-DMA of my image of window slot `slot` (IMG contiguous bytes, served by the XCD's L2)
+    auto dma_window = [&](int slot, int im) __attribute__((always_inline)) {
+        int tid = tid0;
+        FFT_OPAQUE(tid);
+        const unsigned char* src = sbase + (size_t)slot * SLOT + (size_t)s * IMG + (size_t)tid * 16;
+        const unsigned lds = img_lds0 + (unsigned)im * IMG;
+        if (p.nt_mask & 4) {
+            FFT_UNROLL
+            for (int i = 0; i < NCH; i++) FFT_DMA16_L2_NT(src + (size_t)i * NTHR * 16, img_b[im], lds, (unsigned)(i * NTHR + tid) * 16u);
+        } else {
+            FFT_UNROLL
+            for (int i = 0; i < NCH; i++) FFT_DMA16_L2(src + (size_t)i * NTHR * 16, img_b[im], lds, (unsigned)(i * NTHR + tid) * 16u);
+        }
+    };
+
+    // final modulation of the row step: result k of the radix-4 over the classes is due scale * i^(sigma k) (the rounds
+    // deliver the classes rotated by sigma)
+    cpx<T> ck[4];
+    FFT_UNROLL
+    for (int k = 0; k < 4; k++) {
+        const int pw4 = (sigma * k) & 3;
+        ck[k] = mk<T>(pw4 == 0 ? p.scale : pw4 == 2 ? -p.scale : (T)0, pw4 == 1 ? p.scale : pw4 == 3 ? -p.scale : (T)0);
+    }
+
+    dma_chunk(in_of(0), 0, 0);
+    for (int it = 0; it < NTR; it++) {
+        const cpx<T>* inb = in_of(it);
+        cpx<T>* outb = out_of(it);
+        const int G = 4 * it;  // arrivals made before this transform
+
+        // ================= column step: four chunks, length-M transforms, results x W_L^(a kb) kept
+        cpx<T> blk[4][E];
+        FFT_UNROLL
+        for (int a = 0; a < 4; a++) {
+            // my pieces of the chunk have landed (chunk 0: all but the previous transform's 4 E / 2 result stores, which
+            // were issued behind its DMA) ... everybody's have; the other image was last read before this barrier
+            if (a == 0 && it > 0) FFT_WAIT_VM_LE(2 * E);
+            else FFT_WAIT_VM0();
+            FFT_SYNC_LDS();
+            ev();
+            if (a + 1 < 4) dma_chunk(inb, a + 1, (a + 1) & 1);
+            cpx<T>* img = reinterpret_cast<cpx<T>*>(img_b[a & 1]);
+            int t = tid0;
+            FFT_OPAQUE(t);
+            quad_stage1<T, E, LOG2NC, LOG2L, true>(img, wl, t & (NC - 1), t >> LOG2NC, p.inverse != 0);
+            FFT_SYNC_LDS();
+            FFT_OPAQUE(t);
+            const int g = t & (E - 1), c2 = ap + 4 * (((t >> log2E) & 3) + 4 * (t >> (log2E + 4)));
+            cpx<T> v[E];
+            quad_stage2<T, E, LOG2NC>(v, img, (c2 + quad_phi(g)) & (NC - 1), g);
+            if (a == 0) {
+                FFT_UNROLL
+                for (int k = 0; k < E; k++) blk[0][k] = v[k];
+            } else {
+                // W_L^(a (g + E k) - M a ap): the class shift ap rotates the radix-4's OUTPUTS (block r = rows M (r - ap))
+                cpx<T> w[E];
+                quad_powers<T, E>(w, wl[(unsigned)(a * g - M * a * ap) & (L - 1)], wl[(a * E) & (L - 1)]);
+                FFT_UNROLL
+                for (int k = 0; k < E; k++) blk[a][k] = cmul(v[k], w[k]);
+            }
+        }
+        // ---- combine: radix-4 over the chunks, then W_n^(k1 j2), k1 = g + E k + M q, q = (r - ap) mod 4 for block r
+        {
+            int t = tid0;
+            FFT_OPAQUE(t);
+            const int g = t & (E - 1), c2 = ap + 4 * (((t >> log2E) & 3) + 4 * (t >> (log2E + 4)));
+            const unsigned j2 = (unsigned)(NC * s + c2);  // my column of the transform
+            const cpx<T> f1 = wn((unsigned)M * j2), f2 = cmul(f1, f1), f3 = cmul(f2, f1);
+            const cpx<T> base0 = wn((unsigned)g * j2);
+            const cpx<T> sp = wn((unsigned)E * j2);
+            FFT_UNROLL
+            for (int k = 0; k < E; k++) {
+                cpx<T> u[4];
+                FFT_UNROLL
+                for (int a = 0; a < 4; a++) u[a] = blk[a][k];
+                dft_inplace<T, 4>(u);
+                FFT_UNROLL
+                for (int a = 0; a < 4; a++) blk[a][k] = u[a];
+            }
+            FFT_UNROLL
+            for (int r = 0; r < 4; r++) {
+                const int q = (r - ap) & 3;  // wave-uniform
+                const cpx<T> fq = mk<T>(q == 0 ? (T)1 : q == 1 ? f1.re : q == 2 ? f2.re : f3.re, q == 0 ? (T)0 : q == 1 ? f1.im : q == 2 ? f2.im : f3.im);
+                cpx<T> w[E];
+                quad_powers<T, E>(w, cmul(base0, fq), sp);
+                FFT_UNROLL
+                for (int k = 0; k < E; k++) blk[r][k] = cmul(blk[r][k], w[k]);
+            }
+        }
+        ev();
+
+        // ================= exchange + row step
+        // block r of my registers goes out in round r: rows k1 = g + E k + M q of column j2, to the seats of row block q
+        auto send = [&](int r) __attribute__((always_inline)) {
+            int t = tid0;
+            FFT_OPAQUE(t);
+            const int g = t & (E - 1), cc = ((t >> log2E) & 3) + 4 * (t >> (log2E + 4));
+            const int q = (r - ap) & 3;
+            unsigned char* const wslot = sbase + (size_t)(r & 1) * SLOT;
+            const bool odd = (g & 1) != 0;
+            const int bprime = (NC / 4) * s + cc;  // (j2 - ap) / 4: my column's place in its class
+            FFT_UNROLL
+            for (int i = 0; i < E / 2; i++) {
+                vec16<T> v;
+                pair_rows<T>(blk[r][2 * i], blk[r][2 * i + 1], odd, 1, v);  // even lane: rows (g, g + 1) of slot 2 i; odd lane: rows (g - 1, g) of slot 2 i + 1
+                const int k1 = (g & ~1) + E * (2 * i + (odd ? 1 : 0)) + M * q;
+                const int dst_seat = k1 >> LOG2NC, rho = k1 & (NC - 1);
+                *reinterpret_cast<vec16<T>*>(wslot + (size_t)dst_seat * IMG + (size_t)(((bprime << LOG2NC) + rho) * SZ)) = v;
+            }
+        };
+        send(0);
+        FFT_WAIT_VM0();
+        FFT_SYNC_LDS();
+        arrive();  // arrival G + 1: my round-0 values are in L2 (and my image of the previous transform's round 3 has long landed)
+        ev();
+        cpx<T> zt[4][E];
+        FFT_UNROLL
+        for (int r = 0; r < 4; r++) {
+            wait_all(G + r + 1);  // everybody's round-r values are in L2; everybody's image of round r - 1 has landed
+            ev();
+            dma_window(r & 1, r & 1);
+            if (r < 3) send(r + 1);  // into the slot whose last readers (round r - 1) are done
+            if (r < 3) FFT_WAIT_VM_LE(E / 2);
+            else FFT_WAIT_VM0();
+            FFT_SYNC_LDS();  // the round's image has landed, everybody's
+            ev();
+            if (r == 3 && it + 1 < NTR) dma_chunk(in_of(it + 1), 0, 0);  // image 0 was last read in round 2
+            cpx<T>* img = reinterpret_cast<cpx<T>*>(img_b[r & 1]);
+            int t = tid0;
+            FFT_OPAQUE(t);
+            quad_stage1<T, E, LOG2NC, LOG2L, false>(img, wl, t & (NC - 1), t >> LOG2NC, false);
+            if (r < 3) FFT_WAIT_VM0();  // my round-(r + 1) values are in L2
+            FFT_SYNC_LDS();
+            if (r < 3) arrive();  // arrival G + r + 2
+            FFT_OPAQUE(t);
+            const int nr = t >> LOG2NC;
+            cpx<T> v[E];
+            quad_stage2<T, E, LOG2NC>(v, img, t & (NC - 1), nr);
+            const int apr = (r - sigma) & 3;  // the class this round delivered (workgroup-uniform)
+            if (apr != 0) {
+                cpx<T> w[E];
+                quad_powers<T, E>(w, wl[(apr * nr) & (L - 1)], wl[(apr * E) & (L - 1)]);
+                FFT_UNROLL
+                for (int k = 0; k < E; k++) zt[r][k] = cmul(v[k], w[k]);
+            } else {
+                FFT_UNROLL
+                for (int k = 0; k < E; k++) zt[r][k] = v[k];
+            }
+        }
+        // ---- final radix-4 over the rounds, modulation, transposed store: X[k1 + L k2], k1 = NC s + rho, k2 = g' + E k + M ka
+        {
+            int t = tid0;
+            FFT_OPAQUE(t);
+            const int ncol = t & (NC - 1), nr = t >> LOG2NC;
+            const bool odd = (ncol & 1) != 0;
+            FFT_UNROLL
+            for (int k = 0; k < E; k++) {
+                cpx<T> u[4];
+                FFT_UNROLL
+                for (int r = 0; r < 4; r++) u[r] = zt[r][k];
+                dft_inplace<T, 4>(u);
+                FFT_UNROLL
+                for (int r = 0; r < 4; r++) {
+                    u[r] = cmul(u[r], ck[r]);
+                    zt[r][k] = p.inverse ? cswap(u[r]) : u[r];
+                }
+            }
+            ev();
+            cpx<T>* const line0 = outb + NC * s + (ncol & ~1);
+            FFT_UNROLL
+            for (int ka = 0; ka < 4; ka++) {
+                FFT_UNROLL
+                for (int i = 0; i < E / 2; i++) {
+                    vec16<T> v;
+                    pair_rows<T>(zt[ka][2 * i], zt[ka][2 * i + 1], odd, 1, v);
+                    const long long k2 = nr + E * (2 * i + (odd ? 1 : 0)) + M * ka;
+                    vec16<T>* const dst = reinterpret_cast<vec16<T>*>(line0 + (k2 << LOG2L));
+                    if (p.nt_mask & 2) FFT_STORE16_NT(dst, v);
+                    else *dst = v;
+                }
+            }
+        }
+        ev();
+    }
+}
+
+}  // namespace fftk

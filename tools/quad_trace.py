@@ -1,0 +1,54 @@
+"""Timeline of team_quad_kernel (fft_team_quad.h) from its in-kernel clock log.  python tools/quad_trace.py [batch]
+Events per workgroup: 0 = team formed; per transform 16: the four column chunks landed, combine done, round-0 values in L2
+(arrival), then per round: team wait over, image landed; final radix-4 done, result stores issued."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "fft-implementation-in-c_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import fftlib  # noqa: E402
+import oracle_lib as O  # noqa: E402
+
+NAMES = ["chunk0 landed", "chunk1 landed", "chunk2 landed", "chunk3 landed", "combine done", "send0 in L2",
+         "wait0 over", "img0 landed", "wait1 over", "img1 landed", "wait2 over", "img2 landed", "wait3 over", "img3 landed",
+         "radix-4 done", "stores issued"]
+
+
+def main():
+    batch = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+    n = 1 << 20
+    fftlib.init()
+    x = O.gen_lcg(n, 3, 8).astype(np.complex64)
+    x = np.tile(x, (batch // 8, 1))
+    buf, out = fftlib.DeviceBuffer(x.nbytes), fftlib.DeviceBuffer(x.nbytes)
+    buf.upload(x)
+    plan = fftlib.Plan(n, batch, -1, np.complex64)
+    NTR = 8
+    events = 1 + 16 * NTR + 1
+    tr = fftlib.DeviceBuffer(256 * events * 8)
+    tr.upload(np.zeros(256 * events, dtype=np.int64))
+    plan.timed(buf.ptr, out.ptr, 3)
+    ms = plan.timed(buf.ptr, out.ptr, 10) / 10
+    print("n=2^20 batch %d: %.3f ms = %.1f Gpoint/s (%.2f us per transform per team)" % (batch, ms, n * batch / ms / 1e6, ms * 1e3 / (batch / 8)))
+    plan.lib.fft_gpu_plan_team_trace_hip(plan.handle, tr.ptr, events)
+    plan.execute_ptr(buf.ptr, out.ptr)
+    print("status", plan.team_status())
+    t = tr.download((256, events), np.int64).astype(np.float64) / 100.0  # us
+    print("team formation: spread %.2f us" % (t[:, 0].max() - t[:, 0].min()))
+    for it in (2, 5):
+        base = 1 + 16 * it
+        prev = t[:, base - 1]
+        print("transform #%d of each team: event, mean delta us over 256 workgroups (min..max), cumulative" % it)
+        cum = 0.0
+        for i, nm in enumerate(NAMES):
+            d = t[:, base + i] - prev
+            cum += d.mean()
+            print("  %-14s %7.2f  (%6.2f .. %6.2f)   %7.2f" % (nm, d.mean(), d.min(), d.max(), cum))
+            prev = t[:, base + i]
+
+
+if __name__ == "__main__":
+    main()
