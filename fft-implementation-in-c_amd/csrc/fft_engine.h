@@ -222,9 +222,13 @@ class Pow2Plan {
         const int mode = rt->policy.team_mode;
         if (mode <= 0 || SZ != 8 || (log2n & 1)) return;
         const int E = quad_E(log2n);
-        if (!E || !rt->team_quad(SZ, log2n)) return;
+        // 0: no; 1: one 512-thread workgroup per CU (teams of 32 at n = 2^20); 2: TWO 256-thread workgroups per CU (teams of
+        // 64, 128-byte row segments): the two run out of step, one's arithmetic fills the other's LDS and barrier waits
+        const int variant = E ? rt->team_quad(SZ, log2n) : 0;
+        if (!variant) return;
         TeamDesc<T> d;
         if (!rt->team_geometry(d.log2seats, d.n_xcc, d.nthreads)) return;
+        if (variant == 2) { d.log2seats += 1; d.nthreads /= 2; }
         const int log2L = log2n / 2;
         const long long L = 1ll << log2L;
         if (L != 4ll * E * E) return;
@@ -233,7 +237,7 @@ class Pow2Plan {
         if (d.log2TS < 2 || d.log2TS > d.log2seats) return;
         if ((L >> d.log2TS) * E != d.nthreads || (L >> d.log2TS) < 16) return;
 #if !defined(FFT_EMU)
-        if (!(log2n == 20 && d.log2TS == 5)) return;  // the device instantiation
+        if (!(log2n == 20 && (d.log2TS == 5 || d.log2TS == 6))) return;  // the device instantiations
 #else
         if (!(log2n == 12 && d.log2TS == 2)) return;  // the emulation's instantiation
 #endif
@@ -245,13 +249,16 @@ class Pow2Plan {
         d.n_teams = d.n_xcc << (d.log2seats - d.log2TS);
         if (d.n_teams > fftk::TEAM_CTL_MAX_TEAMS) return;
         d.data_bytes = 2 * (SZ << log2TE);
-        d.tables_elems = (int)(2 * L);
+        d.tables_elems = (int)(L / 2 + L);  // what the kernel keeps in LDS: [W_n^x, x < L/2 | W_L^y, y < L]; W_n^(L/2) follows in the blob
         d.smem_bytes = d.data_bytes + d.tables_elems * SZ + 16;
-        if (d.smem_bytes > rt->max_lds_bytes()) return;
+        if (d.smem_bytes * (variant == 2 ? 2 : 1) > rt->max_lds_bytes()) return;
         std::vector<cpx<T>> blob, part;
-        make_twiddle_table<T>(blob, L * L, L, 1);
+        make_twiddle_table<T>(blob, L * L, L / 2, 1);
         make_twiddle_table<T>(part, L, L, 1);
         blob.insert(blob.end(), part.begin(), part.end());
+        make_twiddle_table<T>(part, L * L, 2, L / 2);
+        blob.push_back(part[1]);
+        blob.push_back(part[0]);  // (pad to 16 bytes)
         d.scratch_bytes = ((size_t)SZ << (log2TE + d.log2TS)) * 2 * (size_t)d.n_teams;
         d.tables = (cpx<T>*)rt->dmalloc(blob.size() * SZ);
         d.scratch = (unsigned char*)rt->dmalloc(d.scratch_bytes);
@@ -276,7 +283,8 @@ class Pow2Plan {
 #if defined(FFT_EMU)
             rt->launch_coresident(fftk::team_quad_kernel<T, 4, 6, 2>, grid, team.nthreads, (size_t)team.smem_bytes, tp);
 #else
-            rt->launch_coresident(fftk::team_quad_kernel<T, 16, 10, 5>, grid, team.nthreads, (size_t)team.smem_bytes, tp);
+            if (team.log2TS == 6) rt->launch_coresident(fftk::team_quad_kernel<T, 16, 10, 6>, grid, team.nthreads, (size_t)team.smem_bytes, tp);
+            else rt->launch_coresident(fftk::team_quad_kernel<T, 16, 10, 5>, grid, team.nthreads, (size_t)team.smem_bytes, tp);
 #endif
         }
         (void)grid;

@@ -29,6 +29,22 @@
 
 #include "fft_team_quad_decl.h"
 
+// build switches (same-box A/B with tools/ab_quad.sh; the defaults are what measured fastest, profiles/r3_ab_quad.txt:
+// table twiddles -3.5 % (LDS latency at two waves per SIMD), shared-power combine +-0, early send +0.5 %, pipelined rounds
+// with the arrival at B1 +7 %, at B2 -4.6 %)
+#ifndef QUAD_TW_TABLE   // 1: twiddles whose index is (nearly) wave-uniform are read from the LDS table (broadcast reads); 0: powers
+#define QUAD_TW_TABLE 0
+#endif
+#ifndef QUAD_COMBINE    // 1: inter-step twiddle as (x * sp^k) * base_r with shared powers (independent products); 0: a power tree per block
+#define QUAD_COMBINE 0
+#endif
+#ifndef QUAD_ARR5       // 1: a fifth arrival per transform ("my image of round 3 has landed") lets round 1's values go out before the first team wait
+#define QUAD_ARR5 1
+#endif
+#ifndef QUAD_SPREAD     // 1 / 2: the last quarter / half of a transform's result stores goes out under the next transform's first / first two column chunks
+#define QUAD_SPREAD 0
+#endif
+
 namespace fftk {
 
 template <int E, int LOG2L, int LOG2TS>
@@ -45,7 +61,15 @@ struct QuadShape {
 // of its row.  Stage 1 writes a row with lanes along c (a rotated row is still one contiguous run of banks), stage 2 reads
 // with lanes along g = R / E (E rows, a bank row apart) and four columns: the rotation spreads the E rows over all banks
 // (NC = 32, E = 16: lanes (g, il) -> position 4 il + (g & 3) + 8 (g >> 2) + const: 32 distinct 8-byte slots per half wave).
-FFT_DEVICE int quad_phi(int g) { return (g & 3) + 8 * (g >> 2); }
+template <int NC>
+FFT_DEVICE int quad_phi(int g) { return NC >= 32 ? (g & 3) + 8 * (g >> 2) : ((g >> 1) & 3) + 8 * (g >> 3); }
+// Where image row R is kept: with NC = 16 an image row is 128 bytes = HALF the banks, and the E rows a stage-2 thread group
+// reads (R = E g + r, g = 0..E-1) all start on the same half.  Swapping the rows of a pair where bit log2 E of R is set puts
+// the rows of even and odd g on different halves (NC = 16: lanes (g, il) -> half (r ^ g) & 1, position 4 il + ((g >> 1) & 3)
+// + 8 (g >> 3) + const: conflict-free; the natural-map stage 2 of the row step likewise).  An involution; the rows a
+// stage-1 thread writes (r + E k) are the slots its own wave has just read.
+template <int NC, int E>
+FFT_DEVICE int quad_slot(int R) { return NC >= 32 ? R : R ^ ((R >> Log2<E>::value) & 1); }
 
 // w[e] = base * step^e, e < E: E - 1 products at most log2 E deep
 template <typename T, int E>
@@ -67,24 +91,31 @@ FFT_DEVICE void quad_stage1(cpx<T>* img, const cpx<T>* wl, int col, int r, bool 
     constexpr int W = 1 << LOG2W, L = 1 << LOG2L;
     cpx<T> x[E];
     FFT_UNROLL
-    for (int e = 0; e < E; e++) x[e] = img[((r + E * e) << LOG2W) + col];
+    for (int e = 0; e < E; e++) x[e] = img[(quad_slot<W, E>(r + E * e) << LOG2W) + col];
     if (swap_in) {
         FFT_UNROLL
         for (int e = 0; e < E; e++) x[e] = cswap(x[e]);
     }
     dft_inplace<T, E>(x);
     cpx<T> pw[E];
+#if QUAD_TW_TABLE
+    // r takes two values per wave (lanes run along the image row): broadcast reads, no bank conflicts
+    static_assert(4 * (E - 1) * (E - 1) < L, "no wrap of the table index");
+    FFT_UNROLL
+    for (int k = 1; k < E; k++) pw[k] = wl[4 * r * k];
+#else
     pw[1] = wl[(4 * r) & (L - 1)];
     FFT_UNROLL
     for (int k = 2; k < E; k++) {
         const int hb = 1 << (31 - __builtin_clz((unsigned)k));
         pw[k] = (k == hb) ? cmul(pw[k >> 1], pw[k >> 1]) : cmul(pw[hb], pw[k - hb]);
     }
+#endif
     FFT_UNROLL
     for (int k = 1; k < E; k++) x[k] = cmul(x[k], pw[k]);
-    if (ROT) FFT_WAVE_LOCKSTEP();  // the rotated positions were read by other lanes of this wave
+    if (ROT || W < 32) FFT_WAVE_LOCKSTEP();  // the rotated positions / swapped rows were read by other lanes of this wave
     FFT_UNROLL
-    for (int k = 0; k < E; k++) img[((r + E * k) << LOG2W) + (ROT ? ((col + quad_phi(k)) & (W - 1)) : col)] = x[k];
+    for (int k = 0; k < E; k++) img[(quad_slot<W, E>(r + E * k) << LOG2W) + (ROT ? ((col + quad_phi<W>(k)) & (W - 1)) : col)] = x[k];
 }
 
 // Stage 2: thread g of column `col` takes the E values of rows r + E g (written by stage 1's threads r), radix-E butterfly:
@@ -92,7 +123,7 @@ FFT_DEVICE void quad_stage1(cpx<T>* img, const cpx<T>* wl, int col, int r, bool 
 template <typename T, int E, int LOG2W>
 FFT_DEVICE void quad_stage2(cpx<T> (&v)[E], const cpx<T>* img, int pos, int g) {
     FFT_UNROLL
-    for (int r = 0; r < E; r++) v[r] = img[((r + E * g) << LOG2W) + pos];
+    for (int r = 0; r < E; r++) v[r] = img[(quad_slot<(1 << LOG2W), E>(r + E * g) << LOG2W) + pos];
     dft_inplace<T, E>(v);
 }
 
@@ -120,8 +151,8 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(E, LOG2L, LOG2TS) team_quad_kernel(TeamParams<T>
         vec16<T>* dst = reinterpret_cast<vec16<T>*>(tab_bytes);
         for (int i = tid; i < (p.tables_bytes >> 4); i += NTHR) dst[i] = src[i];
     }
-    const cpx<T>* const t0 = reinterpret_cast<const cpx<T>*>(tab_bytes);  // W_n^x, x < L
-    const cpx<T>* const wl = t0 + L;                                       // W_L^y, y < L (also W_n^(L y))
+    const cpx<T>* const t0 = reinterpret_cast<const cpx<T>*>(tab_bytes);  // W_n^x, x < L / 2 (12 KiB of tables: two workgroups per CU fit)
+    const cpx<T>* const wl = t0 + L / 2;                                   // W_L^y, y < L (also W_n^(L y))
     unsigned* const sh = reinterpret_cast<unsigned*>(tab_bytes + p.tables_bytes);  // [slot, xcc, ok, timed out]
 
     // ---- team formation (team_form, fft_team.h)
@@ -181,7 +212,12 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(E, LOG2L, LOG2TS) team_quad_kernel(TeamParams<T>
     //   g = t & (E - 1), il = (t >> log2E) & 3, wq = t >> (log2E + 2): ap = wq & 3, cc = il + 4 (wq >> 2), c2 = ap + 4 cc
     const int ap = FFT_UNIFORM((tid >> (log2E + 2)) & 3);
     const int sigma = s >> (LOG2TS - 2);          // my block of rows: k1 in [M sigma, M sigma + M)
-    auto wn = [&](unsigned x) __attribute__((always_inline)) { return cmul(t0[x & (L - 1)], wl[(x >> LOG2L) & (L - 1)]); };  // W_n^x
+    const cpx<T> whalf = p.tables[L / 2 + L];  // W_n^(L/2), behind the two tables in the blob
+    auto wn = [&](unsigned x) __attribute__((always_inline)) {  // W_n^x = W_n^(x mod L/2) [* W_n^(L/2)] * W_L^(x / L)
+        const cpx<T> lo = cmul(t0[x & (L / 2 - 1)], wl[(x >> LOG2L) & (L - 1)]);
+        const cpx<T> hi = cmul(lo, whalf);
+        return (x & (L / 2)) ? hi : lo;
+    };
 
     auto in_of = [&](int it) __attribute__((always_inline)) { return p.in + (long long)(team + (long long)it * n_teams) * n; };
     auto out_of = [&](int it) __attribute__((always_inline)) { return p.out + (long long)(team + (long long)it * n_teams) * n; };
@@ -191,8 +227,10 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(E, LOG2L, LOG2TS) team_quad_kernel(TeamParams<T>
     auto dma_chunk = [&](const cpx<T>* inb, int a, int im) __attribute__((always_inline)) {
         int tid = tid0;
         FFT_OPAQUE(tid);
-        const cpx<T>* src = inb + ((long long)(4 * (tid / PPR) + a) << LOG2L) + NC * s + 2 * (tid % PPR);
+        // (NTHR / PPR rows per wave-front of pieces, a multiple of 2 E: the slot swap is the same in every front)
+        const cpx<T>* src = inb + ((long long)(4 * quad_slot<NC, E>(tid / PPR) + a) << LOG2L) + NC * s + 2 * (tid % PPR);
         constexpr long long step = (long long)(4 * (NTHR / PPR)) << LOG2L;
+        static_assert((NTHR / PPR) % (2 * E) == 0 || NC >= 32, "row swap pattern repeats per wave-front");
         const unsigned lds = img_lds0 + (unsigned)im * IMG;
         if (p.nt_mask & 1) {
             FFT_UNROLL
@@ -226,23 +264,48 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(E, LOG2L, LOG2TS) team_quad_kernel(TeamParams<T>
         ck[k] = mk<T>(pw4 == 0 ? p.scale : pw4 == 2 ? -p.scale : (T)0, pw4 == 1 ? p.scale : pw4 == 3 ? -p.scale : (T)0);
     }
 
+    // transposed store of results ka of a row (k2 = g' + E k + M ka): X[k1 + L k2], k1 = NC s + rho; the lanes of rows rho, rho ^ 1
+    // pair up so that every store is 16 bytes and every wave instruction writes whole NC-row segments
+    auto store_results = [&](cpx<T>* outb, const cpx<T> (&y)[E], int ka) __attribute__((always_inline)) {
+        int t = tid0;
+        FFT_OPAQUE(t);
+        const int ncol = t & (NC - 1), nr = t >> LOG2NC;
+        const bool odd = (ncol & 1) != 0;
+        cpx<T>* const line0 = outb + NC * s + (ncol & ~1);
+        FFT_UNROLL
+        for (int i = 0; i < E / 2; i++) {
+            vec16<T> v;
+            pair_rows<T>(y[2 * i], y[2 * i + 1], odd, 1, v);
+            const long long k2 = nr + E * (2 * i + (odd ? 1 : 0)) + M * ka;
+            vec16<T>* const dst = reinterpret_cast<vec16<T>*>(line0 + (k2 << LOG2L));
+            if (p.nt_mask & 2) FFT_STORE16_NT(dst, v);
+            else *dst = v;
+        }
+    };
+    constexpr int NARR = QUAD_ARR5 ? 5 : 4;  // arrivals per transform
+    constexpr int NPEND = QUAD_SPREAD;  // result blocks ka = 4 - NPEND .. 3 of a transform wait for the next one's column chunks 0 .. NPEND - 1
+    cpx<T> pend[NPEND ? NPEND : 1][E];
+
     dma_chunk(in_of(0), 0, 0);
     for (int it = 0; it < NTR; it++) {
         const cpx<T>* inb = in_of(it);
         cpx<T>* outb = out_of(it);
-        const int G = 4 * it;  // arrivals made before this transform
+        const int G = NARR * it;  // arrivals made before this transform
 
         // ================= column step: four chunks, length-M transforms, results x W_L^(a kb) kept
         cpx<T> blk[4][E];
         FFT_UNROLL
         for (int a = 0; a < 4; a++) {
-            // my pieces of the chunk have landed (chunk 0: all but the previous transform's 4 E / 2 result stores, which
-            // were issued behind its DMA) ... everybody's have; the other image was last read before this barrier
-            if (a == 0 && it > 0) FFT_WAIT_VM_LE(2 * E);
+            // my pieces of the chunk have landed ... everybody's have; the other image was last read before this barrier.
+            // What may still be in flight are the result stores of the previous transform issued BEHIND this chunk's DMA
+            // (vmcnt counts in issue order): (4 - NPEND) E / 2 behind chunk 0, E / 2 behind each of chunks 1 .. NPEND
+            if (it > 0 && a == 0) FFT_WAIT_VM_LE((4 - NPEND) * E / 2);
+            else if (it > 0 && a <= NPEND) FFT_WAIT_VM_LE(E / 2);
             else FFT_WAIT_VM0();
             FFT_SYNC_LDS();
             ev();
             if (a + 1 < 4) dma_chunk(inb, a + 1, (a + 1) & 1);
+            if (it > 0 && a < NPEND) store_results(out_of(it - 1), pend[a], 4 - NPEND + a);
             cpx<T>* img = reinterpret_cast<cpx<T>*>(img_b[a & 1]);
             int t = tid0;
             FFT_OPAQUE(t);
@@ -251,18 +314,41 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(E, LOG2L, LOG2TS) team_quad_kernel(TeamParams<T>
             FFT_OPAQUE(t);
             const int g = t & (E - 1), c2 = ap + 4 * (((t >> log2E) & 3) + 4 * (t >> (log2E + 4)));
             cpx<T> v[E];
-            quad_stage2<T, E, LOG2NC>(v, img, (c2 + quad_phi(g)) & (NC - 1), g);
+            quad_stage2<T, E, LOG2NC>(v, img, (c2 + quad_phi<NC>(g)) & (NC - 1), g);
             if (a == 0) {
                 FFT_UNROLL
                 for (int k = 0; k < E; k++) blk[0][k] = v[k];
             } else {
                 // W_L^(a (g + E k) - M a ap): the class shift ap rotates the radix-4's OUTPUTS (block r = rows M (r - ap))
                 cpx<T> w[E];
+#if QUAD_TW_TABLE
+                FFT_UNROLL
+                for (int k = 0; k < E; k++) w[k] = wl[(unsigned)(a * (g + E * k) - M * a * ap) & (L - 1)];
+#else
                 quad_powers<T, E>(w, wl[(unsigned)(a * g - M * a * ap) & (L - 1)], wl[(a * E) & (L - 1)]);
+#endif
                 FFT_UNROLL
                 for (int k = 0; k < E; k++) blk[a][k] = cmul(v[k], w[k]);
             }
         }
+        // block r of my registers goes out in round r: rows k1 = g + E k + M q of column j2, to the seats of row block q
+        auto send = [&](int r) __attribute__((always_inline)) {
+            int t = tid0;
+            FFT_OPAQUE(t);
+            const int g = t & (E - 1), cc = ((t >> log2E) & 3) + 4 * (t >> (log2E + 4));
+            const int q = (r - ap) & 3;
+            unsigned char* const wslot = sbase + (size_t)(r & 1) * SLOT;
+            const bool odd = (g & 1) != 0;
+            const int bprime = (NC / 4) * s + cc;  // (j2 - ap) / 4: my column's place in its class
+            FFT_UNROLL
+            for (int i = 0; i < E / 2; i++) {
+                vec16<T> v;
+                pair_rows<T>(blk[r][2 * i], blk[r][2 * i + 1], odd, 1, v);  // even lane: rows (g, g + 1) of slot 2 i; odd lane: rows (g - 1, g) of slot 2 i + 1
+                const int k1 = (g & ~1) + E * (2 * i + (odd ? 1 : 0)) + M * q;
+                const int dst_seat = k1 >> LOG2NC, rho = k1 & (NC - 1);
+                *reinterpret_cast<vec16<T>*>(wslot + (size_t)dst_seat * IMG + (size_t)(((quad_slot<NC, E>(bprime) << LOG2NC) + rho) * SZ)) = v;
+            }
+        };
         // ---- combine: radix-4 over the chunks, then W_n^(k1 j2), k1 = g + E k + M q, q = (r - ap) mod 4 for block r
         {
             int t = tid0;
@@ -281,69 +367,89 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(E, LOG2L, LOG2TS) team_quad_kernel(TeamParams<T>
                 FFT_UNROLL
                 for (int a = 0; a < 4; a++) blk[a][k] = u[a];
             }
+#if QUAD_COMBINE
+            cpx<T> pk[E];  // sp^k, shared by the four blocks
+            pk[1] = sp;
+            FFT_UNROLL
+            for (int k = 2; k < E; k++) {
+                const int hb = 1 << (31 - __builtin_clz((unsigned)k));
+                pk[k] = (k == hb) ? cmul(pk[k >> 1], pk[k >> 1]) : cmul(pk[hb], pk[k - hb]);
+            }
+#endif
             FFT_UNROLL
             for (int r = 0; r < 4; r++) {
                 const int q = (r - ap) & 3;  // wave-uniform
                 const cpx<T> fq = mk<T>(q == 0 ? (T)1 : q == 1 ? f1.re : q == 2 ? f2.re : f3.re, q == 0 ? (T)0 : q == 1 ? f1.im : q == 2 ? f2.im : f3.im);
+                const cpx<T> base = cmul(base0, fq);
+#if QUAD_COMBINE
+                blk[r][0] = cmul(blk[r][0], base);
+                FFT_UNROLL
+                for (int k = 1; k < E; k++) blk[r][k] = cmul(cmul(blk[r][k], pk[k]), base);
+#else
                 cpx<T> w[E];
-                quad_powers<T, E>(w, cmul(base0, fq), sp);
+                quad_powers<T, E>(w, base, sp);
                 FFT_UNROLL
                 for (int k = 0; k < E; k++) blk[r][k] = cmul(blk[r][k], w[k]);
+#endif
+                if (r == 0) send(0);  // drains under block 1's twiddles
+                if (r == 1) {
+                    // ================= exchange + row step begins: the team learns that my round-0 values are in L2 while I
+                    // still twiddle blocks 2 and 3 (the first team wait absorbs the column step's skew: work behind the
+                    // arrival is free)
+                    if (QUAD_ARR5) wait_all(G);  // everybody's image of the previous transform's round 3 has landed: long true
+                    FFT_WAIT_VM0();
+                    FFT_SYNC_LDS();
+                    arrive();  // arrival G + 1
+                    ev();
+                    if (QUAD_ARR5) send(1);  // slot 1 was last read in that round 3
+                }
             }
         }
         ev();
-
-        // ================= exchange + row step
-        // block r of my registers goes out in round r: rows k1 = g + E k + M q of column j2, to the seats of row block q
-        auto send = [&](int r) __attribute__((always_inline)) {
-            int t = tid0;
-            FFT_OPAQUE(t);
-            const int g = t & (E - 1), cc = ((t >> log2E) & 3) + 4 * (t >> (log2E + 4));
-            const int q = (r - ap) & 3;
-            unsigned char* const wslot = sbase + (size_t)(r & 1) * SLOT;
-            const bool odd = (g & 1) != 0;
-            const int bprime = (NC / 4) * s + cc;  // (j2 - ap) / 4: my column's place in its class
-            FFT_UNROLL
-            for (int i = 0; i < E / 2; i++) {
-                vec16<T> v;
-                pair_rows<T>(blk[r][2 * i], blk[r][2 * i + 1], odd, 1, v);  // even lane: rows (g, g + 1) of slot 2 i; odd lane: rows (g - 1, g) of slot 2 i + 1
-                const int k1 = (g & ~1) + E * (2 * i + (odd ? 1 : 0)) + M * q;
-                const int dst_seat = k1 >> LOG2NC, rho = k1 & (NC - 1);
-                *reinterpret_cast<vec16<T>*>(wslot + (size_t)dst_seat * IMG + (size_t)(((bprime << LOG2NC) + rho) * SZ)) = v;
-            }
-        };
-        send(0);
-        FFT_WAIT_VM0();
-        FFT_SYNC_LDS();
-        arrive();  // arrival G + 1: my round-0 values are in L2 (and my image of the previous transform's round 3 has long landed)
-        ev();
         cpx<T> zt[4][E];
+        wait_all(G + 1);
+        ev();
+        dma_window(0, 0);
+        if (!QUAD_ARR5) send(1);
         FFT_UNROLL
         for (int r = 0; r < 4; r++) {
-            wait_all(G + r + 1);  // everybody's round-r values are in L2; everybody's image of round r - 1 has landed
-            ev();
-            dma_window(r & 1, r & 1);
-            if (r < 3) send(r + 1);  // into the slot whose last readers (round r - 1) are done
-            if (r < 3) FFT_WAIT_VM_LE(E / 2);
-            else FFT_WAIT_VM0();
-            FFT_SYNC_LDS();  // the round's image has landed, everybody's
+            FFT_WAIT_VM0();  // the round's image has landed and my round-(r + 1) values are in L2 ...
+            FFT_SYNC_LDS();  // ... everybody's
+            if (r < 3 || QUAD_ARR5) arrive();  // arrival G + r + 2 (r = 3, QUAD_ARR5: G + 5, "my image of round 3 has landed")
             ev();
             if (r == 3 && it + 1 < NTR) dma_chunk(in_of(it + 1), 0, 0);  // image 0 was last read in round 2
             cpx<T>* img = reinterpret_cast<cpx<T>*>(img_b[r & 1]);
             int t = tid0;
             FFT_OPAQUE(t);
             quad_stage1<T, E, LOG2NC, LOG2L, false>(img, wl, t & (NC - 1), t >> LOG2NC, false);
-            if (r < 3) FFT_WAIT_VM0();  // my round-(r + 1) values are in L2
             FFT_SYNC_LDS();
-            if (r < 3) arrive();  // arrival G + r + 2
             FFT_OPAQUE(t);
             const int nr = t >> LOG2NC;
             cpx<T> v[E];
-            quad_stage2<T, E, LOG2NC>(v, img, t & (NC - 1), nr);
+            {
+                const int pos = t & (NC - 1);
+                FFT_UNROLL
+                for (int rr = 0; rr < E; rr++) v[rr] = img[(quad_slot<NC, E>(rr + E * nr) << LOG2NC) + pos];
+            }
+            if (r < 3) {
+                // the next round's image is requested NOW (the other image was last read in round r - 1) and flies under this
+                // round's second stage; behind it the values of round r + 2, into the slot this round's image came from
+                // (everybody's image of round r has landed: arrival G + r + 2 says so)
+                wait_all(G + r + 2);
+                ev();
+                dma_window((r + 1) & 1, (r + 1) & 1);
+                if (r < 2) send(r + 2);
+            }
+            dft_inplace<T, E>(v);
             const int apr = (r - sigma) & 3;  // the class this round delivered (workgroup-uniform)
             if (apr != 0) {
                 cpx<T> w[E];
+#if QUAD_TW_TABLE
+                FFT_UNROLL
+                for (int k = 0; k < E; k++) w[k] = wl[apr * (nr + E * k)];  // < 3 M: no wrap
+#else
                 quad_powers<T, E>(w, wl[(apr * nr) & (L - 1)], wl[(apr * E) & (L - 1)]);
+#endif
                 FFT_UNROLL
                 for (int k = 0; k < E; k++) zt[r][k] = cmul(v[k], w[k]);
             } else {
@@ -351,37 +457,27 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(E, LOG2L, LOG2TS) team_quad_kernel(TeamParams<T>
                 for (int k = 0; k < E; k++) zt[r][k] = v[k];
             }
         }
-        // ---- final radix-4 over the rounds, modulation, transposed store: X[k1 + L k2], k1 = NC s + rho, k2 = g' + E k + M ka
-        {
-            int t = tid0;
-            FFT_OPAQUE(t);
-            const int ncol = t & (NC - 1), nr = t >> LOG2NC;
-            const bool odd = (ncol & 1) != 0;
+        // ---- final radix-4 over the rounds, modulation, transposed store
+        FFT_UNROLL
+        for (int k = 0; k < E; k++) {
+            cpx<T> u[4];
             FFT_UNROLL
-            for (int k = 0; k < E; k++) {
-                cpx<T> u[4];
-                FFT_UNROLL
-                for (int r = 0; r < 4; r++) u[r] = zt[r][k];
-                dft_inplace<T, 4>(u);
-                FFT_UNROLL
-                for (int r = 0; r < 4; r++) {
-                    u[r] = cmul(u[r], ck[r]);
-                    zt[r][k] = p.inverse ? cswap(u[r]) : u[r];
-                }
+            for (int r = 0; r < 4; r++) u[r] = zt[r][k];
+            dft_inplace<T, 4>(u);
+            FFT_UNROLL
+            for (int r = 0; r < 4; r++) {
+                u[r] = cmul(u[r], ck[r]);
+                zt[r][k] = p.inverse ? cswap(u[r]) : u[r];
             }
-            ev();
-            cpx<T>* const line0 = outb + NC * s + (ncol & ~1);
-            FFT_UNROLL
-            for (int ka = 0; ka < 4; ka++) {
+        }
+        ev();
+        FFT_UNROLL
+        for (int ka = 0; ka < 4; ka++) {
+            if (ka >= 4 - NPEND && it + 1 < NTR) {
                 FFT_UNROLL
-                for (int i = 0; i < E / 2; i++) {
-                    vec16<T> v;
-                    pair_rows<T>(zt[ka][2 * i], zt[ka][2 * i + 1], odd, 1, v);
-                    const long long k2 = nr + E * (2 * i + (odd ? 1 : 0)) + M * ka;
-                    vec16<T>* const dst = reinterpret_cast<vec16<T>*>(line0 + (k2 << LOG2L));
-                    if (p.nt_mask & 2) FFT_STORE16_NT(dst, v);
-                    else *dst = v;
-                }
+                for (int k = 0; k < E; k++) pend[ka - (4 - NPEND) < 0 ? 0 : ka - (4 - NPEND)][k] = zt[ka][k];
+            } else {
+                store_results(outb, zt[ka], ka);
             }
         }
         ev();

@@ -2,5 +2,6 @@
 #include "fft_team_quad.h"
 
 namespace fftk {
-template __global__ void team_quad_kernel<float, 16, 10, 5>(TeamParams<float>);
+template __global__ void team_quad_kernel<float, 16, 10, 5>(TeamParams<float>);  // one 512-thread workgroup per CU, teams of 32
+template __global__ void team_quad_kernel<float, 16, 10, 6>(TeamParams<float>);  // two 256-thread workgroups per CU, teams of 64
 }

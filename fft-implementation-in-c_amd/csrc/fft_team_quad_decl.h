@@ -18,6 +18,7 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(E, LOG2L, LOG2TS) team_quad_kernel(TeamParams<T>
 
 #if !defined(FFT_EMU)
 extern template __global__ void team_quad_kernel<float, 16, 10, 5>(TeamParams<float>);
+extern template __global__ void team_quad_kernel<float, 16, 10, 6>(TeamParams<float>);
 #endif
 
 }  // namespace fftk

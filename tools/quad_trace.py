@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import fftlib  # noqa: E402
 import oracle_lib as O  # noqa: E402
 
-NAMES = ["chunk0 landed", "chunk1 landed", "chunk2 landed", "chunk3 landed", "combine done", "send0 in L2",
+NAMES = ["chunk0 landed", "chunk1 landed", "chunk2 landed", "chunk3 landed", "send0 in L2 (arrive)", "combine done",
          "wait0 over", "img0 landed", "wait1 over", "img1 landed", "wait2 over", "img2 landed", "wait3 over", "img3 landed",
          "radix-4 done", "stores issued"]
 
