@@ -98,6 +98,8 @@ inline void fft_st16(V16* p, const V16& v) { *p = v; }
 // the lanes of a wave run in lock step on the device: LDS writes that follow LDS reads in program order can never overtake
 // another lane's reads.  The emulation's "lanes" are free-running host threads: a workgroup barrier stands in.
 #define FFT_WAVE_LOCKSTEP() emu::sync_threads()
+#define FFT_LDS_LD64(p) (*(p))
+#define FFT_LDS_ST64(p, v) (*(p) = (v))
 #else
 #include <hip/hip_runtime.h>
 #define FFT_KERNEL __global__
@@ -252,6 +254,13 @@ __device__ __forceinline__ void fft_store16_sc1(V16* ptr, const V16& v) {
 }
 #define FFT_WAIT_VM_LE(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")  // at most n of my memory operations still in flight
 #define FFT_WAVE_LOCKSTEP() ((void)0)
+// One 8-byte LDS access that STAYS one ds_read_b64 / ds_write_b64: hipcc otherwise fuses pairs of them into ds_read2_b64 /
+// ds_read2st64_b64 / ds_write2st64_b64, which move half the bytes per clock of the single forms and bank on 32 dwords in
+// 16-lane groups instead of 64 dwords in 32-lane groups (MI355X_MICROARCH.md, LDS table) -- layouts made conflict-free for
+// the single form are 2-way conflicted in the fused one.  Volatile accesses through an explicit LDS pointer are never fused
+// (and, the address space being explicit, never come out as FLAT); hipcc still tracks them in its lgkmcnt bookkeeping.
+#define FFT_LDS_LD64(p) fft_lds_ld64(p)
+#define FFT_LDS_ST64(p, v) fft_lds_st64((p), (v))
 template <int SC1>
 __device__ __forceinline__ void fft_dma16(const void* gsrc, unsigned lane_lds_addr) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -377,6 +386,21 @@ FFT_DEVICE cpx<float> csub_mni(cpx<float> a, cpx<float> b) {  // (a.re - b.im, a
     fft_v2f r;
     asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(as_v2(a)), "v"(as_v2(b)));
     return as_cpx(r);
+}
+#endif
+
+#if !defined(FFT_EMU)
+typedef float fft_lds_v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ cpx<float> fft_lds_ld64(const cpx<float>* p) {
+    const fft_lds_v2f v = *(const volatile __attribute__((address_space(3))) fft_lds_v2f*)(const __attribute__((address_space(3))) void*)p;
+    cpx<float> r;
+    r.re = v.x;
+    r.im = v.y;
+    return r;
+}
+__device__ __forceinline__ void fft_lds_st64(cpx<float>* p, cpx<float> a) {
+    fft_lds_v2f v = {a.re, a.im};
+    *(volatile __attribute__((address_space(3))) fft_lds_v2f*)(__attribute__((address_space(3))) void*)p = v;
 }
 #endif
 

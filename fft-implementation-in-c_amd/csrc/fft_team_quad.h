@@ -41,8 +41,31 @@
 #ifndef QUAD_ARR5       // 1: a fifth arrival per transform ("my image of round 3 has landed") lets round 1's values go out before the first team wait
 #define QUAD_ARR5 1
 #endif
+#ifndef QUAD_MERGE      // 1: team polls whose condition is long true ride on the next workgroup barrier (one barrier fewer per round)
+#define QUAD_MERGE 0
+#endif
+#ifndef QUAD_FINAL      // 1: the result stores are issued pair of rows by pair of rows between the final radix-4 butterflies, not behind them
+#define QUAD_FINAL 1
+#endif
 #ifndef QUAD_SPREAD     // 1 / 2: the last quarter / half of a transform's result stores goes out under the next transform's first / first two column chunks
 #define QUAD_SPREAD 0
+#endif
+
+#ifndef QUAD_LDS_SINGLE  // 1: the stage exchanges use single ds_read_b64 / ds_write_b64 (FFT_LDS_LD64 / ST64), never the fused forms
+#define QUAD_LDS_SINGLE 1
+#endif
+#ifndef QUAD_TW_FIRST    // 1: a stage's twiddle powers are formed in front of its butterflies (under the LDS reads' latency)
+#define QUAD_TW_FIRST 1
+#endif
+#if QUAD_LDS_SINGLE
+#define QUAD_LD(p) FFT_LDS_LD64(p)
+#define QUAD_ST(p, v) FFT_LDS_ST64((p), (v))
+#else
+#define QUAD_LD(p) (*(p))
+#define QUAD_ST(p, v) (*(p) = (v))
+#endif
+#ifndef QUAD_FINE_TRACE  // profiling builds only: time stamps inside the chunks of transform 3 (tools/quad_fine.py)
+#define QUAD_FINE_TRACE 0
 #endif
 
 namespace fftk {
@@ -86,17 +109,16 @@ FFT_DEVICE void quad_powers(cpx<T> (&w)[E], cpx<T> base, cpx<T> sp) {
 // Stage 1 of a length-M = E^2 transform of column `col` of the image (rows of W = 2^LOG2W values): thread r takes rows
 // r + E e, radix-E butterfly, twiddle W_M^(r k) = W_L^(4 r k) by powers of one table value, results written IN PLACE
 // (rows r + E k: the rows it has just read; ROT: at the rotated position, read by lanes of the same wave only).
-template <typename T, int E, int LOG2W, int LOG2L, bool ROT>
-FFT_DEVICE void quad_stage1(cpx<T>* img, const cpx<T>* wl, int col, int r, bool swap_in) {
+struct QuadNoMark {
+    FFT_DEVICE void operator()(int) const {}
+};
+template <typename T, int E, int LOG2W, int LOG2L, bool ROT, class Mark = QuadNoMark>
+FFT_DEVICE void quad_stage1(cpx<T>* img, const cpx<T>* wl, int col, int r, bool swap_in, Mark&& mark = QuadNoMark()) {
     constexpr int W = 1 << LOG2W, L = 1 << LOG2L;
     cpx<T> x[E];
     FFT_UNROLL
-    for (int e = 0; e < E; e++) x[e] = img[(quad_slot<W, E>(r + E * e) << LOG2W) + col];
-    if (swap_in) {
-        FFT_UNROLL
-        for (int e = 0; e < E; e++) x[e] = cswap(x[e]);
-    }
-    dft_inplace<T, E>(x);
+    for (int e = 0; e < E; e++) x[e] = QUAD_LD(&img[(quad_slot<W, E>(r + E * e) << LOG2W) + col]);
+#if QUAD_TW_FIRST
     cpx<T> pw[E];
 #if QUAD_TW_TABLE
     // r takes two values per wave (lanes run along the image row): broadcast reads, no bank conflicts
@@ -111,11 +133,42 @@ FFT_DEVICE void quad_stage1(cpx<T>* img, const cpx<T>* wl, int col, int r, bool 
         pw[k] = (k == hb) ? cmul(pw[k >> 1], pw[k >> 1]) : cmul(pw[hb], pw[k - hb]);
     }
 #endif
+    if (swap_in) {
+        FFT_UNROLL
+        for (int e = 0; e < E; e++) x[e] = cswap(x[e]);
+    }
+    mark(1);  // (waits for the reads)
+    dft_inplace<T, E>(x);
+    mark(0);
+#else
+    if (swap_in) {
+        FFT_UNROLL
+        for (int e = 0; e < E; e++) x[e] = cswap(x[e]);
+    }
+    mark(1);  // (waits for the reads)
+    dft_inplace<T, E>(x);
+    mark(0);
+    cpx<T> pw[E];
+#if QUAD_TW_TABLE
+    // r takes two values per wave (lanes run along the image row): broadcast reads, no bank conflicts
+    static_assert(4 * (E - 1) * (E - 1) < L, "no wrap of the table index");
+    FFT_UNROLL
+    for (int k = 1; k < E; k++) pw[k] = wl[4 * r * k];
+#else
+    pw[1] = wl[(4 * r) & (L - 1)];
+    FFT_UNROLL
+    for (int k = 2; k < E; k++) {
+        const int hb = 1 << (31 - __builtin_clz((unsigned)k));
+        pw[k] = (k == hb) ? cmul(pw[k >> 1], pw[k >> 1]) : cmul(pw[hb], pw[k - hb]);
+    }
+#endif
+#endif
     FFT_UNROLL
     for (int k = 1; k < E; k++) x[k] = cmul(x[k], pw[k]);
+    mark(0);
     if (ROT || W < 32) FFT_WAVE_LOCKSTEP();  // the rotated positions / swapped rows were read by other lanes of this wave
     FFT_UNROLL
-    for (int k = 0; k < E; k++) img[(quad_slot<W, E>(r + E * k) << LOG2W) + (ROT ? ((col + quad_phi<W>(k)) & (W - 1)) : col)] = x[k];
+    for (int k = 0; k < E; k++) QUAD_ST(&img[(quad_slot<W, E>(r + E * k) << LOG2W) + (ROT ? ((col + quad_phi<W>(k)) & (W - 1)) : col)], x[k]);
 }
 
 // Stage 2: thread g of column `col` takes the E values of rows r + E g (written by stage 1's threads r), radix-E butterfly:
@@ -123,7 +176,7 @@ FFT_DEVICE void quad_stage1(cpx<T>* img, const cpx<T>* wl, int col, int r, bool 
 template <typename T, int E, int LOG2W>
 FFT_DEVICE void quad_stage2(cpx<T> (&v)[E], const cpx<T>* img, int pos, int g) {
     FFT_UNROLL
-    for (int r = 0; r < E; r++) v[r] = img[(quad_slot<(1 << LOG2W), E>(r + E * g) << LOG2W) + pos];
+    for (int r = 0; r < E; r++) v[r] = QUAD_LD(&img[(quad_slot<(1 << LOG2W), E>(r + E * g) << LOG2W) + pos]);
     dft_inplace<T, E>(v);
 }
 
@@ -198,6 +251,23 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(E, LOG2L, LOG2TS) team_quad_kernel(TeamParams<T>
             }
         }
         FFT_SYNC_LDS();
+    };
+    // the same poll WITHOUT the barrier: the first wave spins, the others walk on -- to the workgroup barrier the caller has next
+    // anyway (which then also publishes "everybody has arrived" to them).  For waits whose condition is normally long true.
+    auto poll_all = [&](int g) __attribute__((always_inline)) {
+        FFT_LDS_FRESH();
+        if (sh[3]) return;
+        if (tid < FFT_TEAM_POLL_LANES) {
+            const long long tstart = FFT_CLOCK();
+            while ((int)(FFT_L2_COUNT_POLL(flags) - ((unsigned)g << LOG2TS)) < 0) {
+                if (FFT_CLOCK() - tstart > p.timeout_ticks) {
+                    team_report_timeout(p);
+                    sh[3] = 1;
+                    break;
+                }
+                FFT_SLEEP();
+            }
+        }
     };
     auto arrive = [&]() __attribute__((always_inline)) {  // call behind a workgroup barrier, every wave's stores complete
         if (tid == 0) FFT_L2_COUNT_ADD(flags);
@@ -309,12 +379,41 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(E, LOG2L, LOG2TS) team_quad_kernel(TeamParams<T>
             cpx<T>* img = reinterpret_cast<cpx<T>*>(img_b[a & 1]);
             int t = tid0;
             FFT_OPAQUE(t);
+#if QUAD_FINE_TRACE
+            // stamps of every wave's first lane inside the chunks of transform 3: p.trace[((block * 8 + wave) * 64) + i]
+            int n_fine = a * 12;
+            auto fine = [&](int drain) __attribute__((always_inline)) {
+                if (it != 3 || !p.trace) return;
+                FFT_SCHED_BARRIER();
+                if (drain) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if ((tid0 & 63) == 0) p.trace[((long long)FFT_BID * 8 + (tid0 >> 6)) * 64 + n_fine] = FFT_CLOCK();
+                n_fine++;
+                FFT_SCHED_BARRIER();
+            };
+            fine(0);  // 0: B1 passed
+            quad_stage1<T, E, LOG2NC, LOG2L, true>(img, wl, t & (NC - 1), t >> LOG2NC, p.inverse != 0, fine);  // 1 reads landed, 2 dft, 3 twiddle
+            fine(1);  // 4: writes done
+            FFT_SYNC_LDS();
+            fine(0);  // 5: B2 passed
+            FFT_OPAQUE(t);
+            const int g = t & (E - 1), c2 = ap + 4 * (((t >> log2E) & 3) + 4 * (t >> (log2E + 4)));
+            cpx<T> v[E];
+            {
+                const int pos = (c2 + quad_phi<NC>(g)) & (NC - 1);
+                FFT_UNROLL
+                for (int rr = 0; rr < E; rr++) v[rr] = QUAD_LD(&img[(quad_slot<NC, E>(rr + E * g) << LOG2NC) + pos]);
+            }
+            fine(1);  // 6: stage-2 reads landed
+            dft_inplace<T, E>(v);
+            fine(0);  // 7: dft
+#else
             quad_stage1<T, E, LOG2NC, LOG2L, true>(img, wl, t & (NC - 1), t >> LOG2NC, p.inverse != 0);
             FFT_SYNC_LDS();
             FFT_OPAQUE(t);
             const int g = t & (E - 1), c2 = ap + 4 * (((t >> log2E) & 3) + 4 * (t >> (log2E + 4)));
             cpx<T> v[E];
             quad_stage2<T, E, LOG2NC>(v, img, (c2 + quad_phi<NC>(g)) & (NC - 1), g);
+#endif
             if (a == 0) {
                 FFT_UNROLL
                 for (int k = 0; k < E; k++) blk[0][k] = v[k];
@@ -330,6 +429,9 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(E, LOG2L, LOG2TS) team_quad_kernel(TeamParams<T>
                 FFT_UNROLL
                 for (int k = 0; k < E; k++) blk[a][k] = cmul(v[k], w[k]);
             }
+#if QUAD_FINE_TRACE
+            fine(0);  // 8: chunk twiddle
+#endif
         }
         // block r of my registers goes out in round r: rows k1 = g + E k + M q of column j2, to the seats of row block q
         auto send = [&](int r) __attribute__((always_inline)) {
@@ -396,7 +498,10 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(E, LOG2L, LOG2TS) team_quad_kernel(TeamParams<T>
                     // ================= exchange + row step begins: the team learns that my round-0 values are in L2 while I
                     // still twiddle blocks 2 and 3 (the first team wait absorbs the column step's skew: work behind the
                     // arrival is free)
-                    if (QUAD_ARR5) wait_all(G);  // everybody's image of the previous transform's round 3 has landed: long true
+                    if (QUAD_ARR5) {  // everybody's image of the previous transform's round 3 has landed: long true
+                        if (QUAD_MERGE) poll_all(G);
+                        else wait_all(G);
+                    }
                     FFT_WAIT_VM0();
                     FFT_SYNC_LDS();
                     arrive();  // arrival G + 1
@@ -422,16 +527,25 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(E, LOG2L, LOG2TS) team_quad_kernel(TeamParams<T>
             int t = tid0;
             FFT_OPAQUE(t);
             quad_stage1<T, E, LOG2NC, LOG2L, false>(img, wl, t & (NC - 1), t >> LOG2NC, false);
+            // (QUAD_MERGE: everybody's arrival G + r + 2 was made a whole first stage ago)
+            if (QUAD_MERGE && r < 3) poll_all(G + r + 2);
             FFT_SYNC_LDS();
+            if (QUAD_MERGE && r < 3) {
+                // the next round's image is requested NOW (the other image was last read in round r - 1) and flies under this
+                // round's second stage; behind it the values of round r + 2, into the slot this round's image came from
+                ev();
+                dma_window((r + 1) & 1, (r + 1) & 1);
+                if (r < 2) send(r + 2);
+            }
             FFT_OPAQUE(t);
             const int nr = t >> LOG2NC;
             cpx<T> v[E];
             {
                 const int pos = t & (NC - 1);
                 FFT_UNROLL
-                for (int rr = 0; rr < E; rr++) v[rr] = img[(quad_slot<NC, E>(rr + E * nr) << LOG2NC) + pos];
+                for (int rr = 0; rr < E; rr++) v[rr] = QUAD_LD(&img[(quad_slot<NC, E>(rr + E * nr) << LOG2NC) + pos]);
             }
-            if (r < 3) {
+            if (!QUAD_MERGE && r < 3) {
                 // the next round's image is requested NOW (the other image was last read in round r - 1) and flies under this
                 // round's second stage; behind it the values of round r + 2, into the slot this round's image came from
                 // (everybody's image of round r has landed: arrival G + r + 2 says so)
@@ -458,6 +572,42 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(E, LOG2L, LOG2TS) team_quad_kernel(TeamParams<T>
             }
         }
         // ---- final radix-4 over the rounds, modulation, transposed store
+#if QUAD_FINAL
+        static_assert(NPEND == 0, "QUAD_FINAL stores every block at once");
+        ev();
+        {
+            int t = tid0;
+            FFT_OPAQUE(t);
+            const int ncol = t & (NC - 1), nr = t >> LOG2NC;
+            const bool odd = (ncol & 1) != 0;
+            cpx<T>* const line0 = outb + NC * s + (ncol & ~1);
+            FFT_UNROLL
+            for (int i = 0; i < E / 2; i++) {
+                cpx<T> y[2][4];
+                FFT_UNROLL
+                for (int h = 0; h < 2; h++) {
+                    FFT_UNROLL
+                    for (int r = 0; r < 4; r++) y[h][r] = zt[r][2 * i + h];
+                    dft_inplace<T, 4>(y[h]);
+                    FFT_UNROLL
+                    for (int r = 0; r < 4; r++) {
+                        y[h][r] = cmul(y[h][r], ck[r]);
+                        if (p.inverse) y[h][r] = cswap(y[h][r]);
+                    }
+                }
+                FFT_UNROLL
+                for (int ka = 0; ka < 4; ka++) {
+                    vec16<T> v;
+                    pair_rows<T>(y[0][ka], y[1][ka], odd, 1, v);
+                    const long long k2 = nr + E * (2 * i + (odd ? 1 : 0)) + M * ka;
+                    vec16<T>* const dst = reinterpret_cast<vec16<T>*>(line0 + (k2 << LOG2L));
+                    if (p.nt_mask & 2) FFT_STORE16_NT(dst, v);
+                    else *dst = v;
+                }
+            }
+        }
+        ev();
+#else
         FFT_UNROLL
         for (int k = 0; k < E; k++) {
             cpx<T> u[4];
@@ -480,6 +630,7 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(E, LOG2L, LOG2TS) team_quad_kernel(TeamParams<T>
                 store_results(outb, zt[ka], ka);
             }
         }
+#endif
         ev();
     }
 }

@@ -50,5 +50,50 @@ def main():
             prev = t[:, base + i]
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] == "seats"):
     main()
+
+
+def per_seat():
+    """python tools/quad_trace.py seats: column-step duration by seat (mean over teams and transforms 2..6)"""
+    n = 1 << 20
+    batch = 512
+    fftlib.init()
+    x = O.gen_lcg(n, 3, 8).astype(np.complex64)
+    x = np.tile(x, (batch // 8, 1))
+    buf, out = fftlib.DeviceBuffer(x.nbytes), fftlib.DeviceBuffer(x.nbytes)
+    buf.upload(x)
+    plan = fftlib.Plan(n, batch, -1, np.complex64)
+    NTR = 8
+    events = 1 + 16 * NTR + 1
+    tr = fftlib.DeviceBuffer(256 * events * 8)
+    tr.upload(np.zeros(256 * events, dtype=np.int64))
+    plan.timed(buf.ptr, out.ptr, 3)
+    plan.lib.fft_gpu_plan_team_trace_hip(plan.handle, tr.ptr, events)
+    plan.execute_ptr(buf.ptr, out.ptr)
+    plan.team_status()  # synchronizes the plan's stream
+    raw = tr.download((256, events), np.int64)
+    t = raw.astype(np.float64) / 100.0
+    ident = raw[:, events - 1]
+    team, seat = ident >> 8, ident & 255
+    col = np.zeros(32)
+    chunks = np.zeros((32, 4))
+    lag = np.zeros(32)
+    for it in range(2, 7):
+        base = 1 + 16 * it
+        dur = t[:, base + 4] - t[:, base - 1]  # end of previous transform -> my round-0 values in L2
+        for a in range(4):
+            d = t[:, base + a] - t[:, base + a - 1]
+            for s in range(32):
+                chunks[s, a] += d[seat == s].mean() / 5
+        arr = t[:, base + 4]
+        for s in range(32):
+            col[s] += dur[seat == s].mean() / 5
+            lag[s] += np.mean([arr[(seat == s) & (team == k)].mean() - arr[team == k].mean() for k in sorted(set(team.tolist()))]) / 5
+    print("seat: column step us | chunk0 chunk1 chunk2 chunk3 landed | arrival vs team mean")
+    for s in range(32):
+        print("%2d: %6.2f | %5.2f %5.2f %5.2f %5.2f | %+5.2f" % (s, col[s], chunks[s, 0], chunks[s, 1], chunks[s, 2], chunks[s, 3], lag[s]))
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "seats":
+    per_seat()
