@@ -401,7 +401,8 @@ def main():
     per_pass = []
     if not info.bluestein_m:
         prof = [plan.profile_passes(x.data_ptr(), y.data_ptr(), 6) for _ in range(3)][-1]
-        names = (["team kernel (team_defer_kernel; team_fft_kernel with FFT_HIP_TEAM_DEFER=0)"] + ["fallback pass %d (returns at once)" % i for i in range(8)]) if team else \
+        team_name = {1: "team_fft_kernel", 2: "team_defer_kernel", 3: "team_quad_kernel"}.get(info.team_kernel, "team kernel")
+        names = ([team_name] + ["fallback pass %d (returns at once)" % i for i in range(8)]) if team else \
                 ["tile_fft_kernel pass %d" % i for i in range(8)]
         per_pass = [{"pass": i, "kernel": names[i], "launches_per_step": c, "avg_launch_ms": m / c, "ms_per_step": m}
                     for i, (m, c) in enumerate(prof)]
@@ -427,10 +428,12 @@ def main():
         achieved = bytes_alg_per_step_gpu / (team_ms * 1e-3) / 1e9
         tile_points = 8192 if dtype == "f32" else 4096  # one 64 KiB tile
         team_cus = max(1, n // (info.team_tiles * tile_points))
-        kernel_desc = ("team kernel (csrc/fft_team_defer.h team_defer_kernel, or csrc/fft_team.h team_fft_kernel where the plain "
-                       "schedule measured faster): ONE launch per step transforms all %d transforms, a whole transform per team of "
-                       "%d CUs of one XCD (256 workgroups = %d teams, %d tiles per workgroup and step); the %d multi-pass launches "
-                       "queued behind it as its fallback return at once" % (batch, team_cus, 256 // team_cus, info.team_tiles, launches))
+        team_src = {1: "csrc/fft_team.h team_fft_kernel", 2: "csrc/fft_team_defer.h team_defer_kernel",
+                    3: "csrc/fft_team_quad.h team_quad_kernel (256-byte row segments, both steps decimated in time by 4, the "
+                       "exchange between them in four rounds through the XCD's L2)"}.get(info.team_kernel, "team kernel")
+        kernel_desc = ("%s: ONE launch per step transforms all %d transforms, a whole transform per team of "
+                       "%d CUs of one XCD (256 workgroups = %d teams, %d 64 KiB tiles per workgroup and step); the %d multi-pass launches "
+                       "queued behind it as its fallback return at once" % (team_src, batch, team_cus, 256 // team_cus, info.team_tiles, launches))
     else:
         kernel_desc = ("tile_fft_kernel: one launch per pass per group of %d transforms (%d launches per step); the "
                        "dominant unit of work is the launch SET that carries a group through all %d passes"

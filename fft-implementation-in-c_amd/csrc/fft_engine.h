@@ -259,7 +259,7 @@ class Pow2Plan {
         make_twiddle_table<T>(part, L * L, 2, L / 2);
         blob.push_back(part[1]);
         blob.push_back(part[0]);  // (pad to 16 bytes)
-        d.scratch_bytes = ((size_t)SZ << (log2TE + d.log2TS)) * 2 * (size_t)d.n_teams;
+        d.scratch_bytes = ((size_t)SZ << (log2TE + d.log2TS)) * 3 * (size_t)d.n_teams;  // three window slots per team (the kernel uses two by default)
         d.tables = (cpx<T>*)rt->dmalloc(blob.size() * SZ);
         d.scratch = (unsigned char*)rt->dmalloc(d.scratch_bytes);
         d.sticky = (unsigned*)rt->dmalloc((fftk::TEAM_STICKY_WORDS + fftk::TEAM_CTL_WORDS) * sizeof(unsigned));

@@ -999,6 +999,7 @@ int fft_gpu_plan_info_hip(fft_gpu_plan_t p, fft_gpu_plan_info_t* info) {
         info->algo = core->algo;
         info->chunk_batch = core->chunk;
         info->team_tiles = core->team.ok ? core->team.NT : 0;
+        info->team_kernel = !core->team.ok ? 0 : core->team.quad ? 3 : core->team.defer ? 2 : 1;
         if (core->team.ok) info->workspace_bytes += core->team.scratch_bytes;
         info->workspace_bytes += core->scratch_bytes;
         if (core->algo == ffteng::ALGO_RADIX2_SHFL) {

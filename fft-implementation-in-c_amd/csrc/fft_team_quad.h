@@ -64,6 +64,15 @@
 #define QUAD_LD(p) (*(p))
 #define QUAD_ST(p, v) (*(p) = (v))
 #endif
+#ifndef QUAD_PAIR_DPP    // 1: the row-pair exchange in front of every 16-byte store as v_cndmask_b32_dpp (select and lane swap in one instruction)
+#define QUAD_PAIR_DPP 1
+#endif
+#ifndef QUAD_CK_FOLD     // 1: the final modulation i^(sigma k) rides on the last radix-4's add / subtract pattern, the scale on the inter-step twiddle
+#define QUAD_CK_FOLD 0
+#endif
+#ifndef QUAD_SLOTS       // window slots per team: 2, or 3 (round r in slot r mod 3: every round's values are in L2 a round earlier; the
+#define QUAD_SLOTS 2     // window is 6 MiB per XCD instead of 4).  The planner allocates 3.
+#endif
 #ifndef QUAD_FINE_TRACE  // profiling builds only: time stamps inside the chunks of transform 3 (tools/quad_fine.py)
 #define QUAD_FINE_TRACE 0
 #endif
@@ -109,6 +118,33 @@ FFT_DEVICE void quad_powers(cpx<T> (&w)[E], cpx<T> base, cpx<T> sp) {
 // Stage 1 of a length-M = E^2 transform of column `col` of the image (rows of W = 2^LOG2W values): thread r takes rows
 // r + E e, radix-E butterfly, twiddle W_M^(r k) = W_L^(4 r k) by powers of one table value, results written IN PLACE
 // (rows r + E k: the rows it has just read; ROT: at the rotated position, read by lanes of the same wave only).
+// pair_rows (fft_team.h) for lanes l, l ^ 1 whose parity IS the row parity: even lane <- (own s0, partner's s0), odd lane <-
+// (partner's s1, own s1).  Device: four v_cndmask_b32_dpp (D = vcc ? src1 : quad_perm[1,0,3,2](src0)) instead of six selects and
+// two DPP moves; hand-written, so the two wait states a DPP read needs behind a vector write of its source are spelled out.
+template <typename T>
+FFT_DEVICE void quad_pair(cpx<T> s0, cpx<T> s1, bool odd, vec16<T>& out) {
+#if QUAD_PAIR_DPP && !defined(FFT_EMU)
+    float a, b, c, d;
+    asm("s_nop 1\n\t"
+        "s_mov_b64 vcc, %8\n\t"
+        "v_cndmask_b32_dpp %0, %6, %4, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32_dpp %1, %7, %5, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_mov_b64 vcc, %9\n\t"
+        "v_cndmask_b32_dpp %2, %4, %6, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32_dpp %3, %5, %7, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+        : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d)
+        : "v"(s0.re), "v"(s0.im), "v"(s1.re), "v"(s1.im), "s"(0x5555555555555555ull), "s"(0xAAAAAAAAAAAAAAAAull)
+        : "vcc");
+    (void)odd;
+    out.c[0].re = a;
+    out.c[0].im = b;
+    out.c[1].re = c;
+    out.c[1].im = d;
+#else
+    pair_rows<T>(s0, s1, odd, 1, out);
+#endif
+}
+
 struct QuadNoMark {
     FFT_DEVICE void operator()(int) const {}
 };
@@ -221,7 +257,7 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(E, LOG2L, LOG2TS) team_quad_kernel(TeamParams<T>
     if (NTR == 0) return;
     if (FFT_TEST_DROP()) return;  // emulation only: a member that never arrives
 
-    unsigned char* const sbase = p.scratch + (size_t)team * 2 * SLOT;
+    unsigned char* const sbase = p.scratch + (size_t)team * 3 * SLOT;  // (three slots allocated; QUAD_SLOTS of them used)
     unsigned* const flags = p.ctl + TEAM_CTL_FLAGS + 32 * team;
 
     int n_ev = 0;
@@ -331,7 +367,8 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(E, LOG2L, LOG2TS) team_quad_kernel(TeamParams<T>
     FFT_UNROLL
     for (int k = 0; k < 4; k++) {
         const int pw4 = (sigma * k) & 3;
-        ck[k] = mk<T>(pw4 == 0 ? p.scale : pw4 == 2 ? -p.scale : (T)0, pw4 == 1 ? p.scale : pw4 == 3 ? -p.scale : (T)0);
+        const T sc = QUAD_CK_FOLD ? (T)1 : p.scale;
+        ck[k] = mk<T>(pw4 == 0 ? sc : pw4 == 2 ? -sc : (T)0, pw4 == 1 ? sc : pw4 == 3 ? -sc : (T)0);
     }
 
     // transposed store of results ka of a row (k2 = g' + E k + M ka): X[k1 + L k2], k1 = NC s + rho; the lanes of rows rho, rho ^ 1
@@ -345,7 +382,7 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(E, LOG2L, LOG2TS) team_quad_kernel(TeamParams<T>
         FFT_UNROLL
         for (int i = 0; i < E / 2; i++) {
             vec16<T> v;
-            pair_rows<T>(y[2 * i], y[2 * i + 1], odd, 1, v);
+            quad_pair<T>(y[2 * i], y[2 * i + 1], odd, v);
             const long long k2 = nr + E * (2 * i + (odd ? 1 : 0)) + M * ka;
             vec16<T>* const dst = reinterpret_cast<vec16<T>*>(line0 + (k2 << LOG2L));
             if (p.nt_mask & 2) FFT_STORE16_NT(dst, v);
@@ -439,13 +476,13 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(E, LOG2L, LOG2TS) team_quad_kernel(TeamParams<T>
             FFT_OPAQUE(t);
             const int g = t & (E - 1), cc = ((t >> log2E) & 3) + 4 * (t >> (log2E + 4));
             const int q = (r - ap) & 3;
-            unsigned char* const wslot = sbase + (size_t)(r & 1) * SLOT;
+            unsigned char* const wslot = sbase + (size_t)(r % QUAD_SLOTS) * SLOT;
             const bool odd = (g & 1) != 0;
             const int bprime = (NC / 4) * s + cc;  // (j2 - ap) / 4: my column's place in its class
             FFT_UNROLL
             for (int i = 0; i < E / 2; i++) {
                 vec16<T> v;
-                pair_rows<T>(blk[r][2 * i], blk[r][2 * i + 1], odd, 1, v);  // even lane: rows (g, g + 1) of slot 2 i; odd lane: rows (g - 1, g) of slot 2 i + 1
+                quad_pair<T>(blk[r][2 * i], blk[r][2 * i + 1], odd, v);  // even lane: rows (g, g + 1) of slot 2 i; odd lane: rows (g - 1, g) of slot 2 i + 1
                 const int k1 = (g & ~1) + E * (2 * i + (odd ? 1 : 0)) + M * q;
                 const int dst_seat = k1 >> LOG2NC, rho = k1 & (NC - 1);
                 *reinterpret_cast<vec16<T>*>(wslot + (size_t)dst_seat * IMG + (size_t)(((quad_slot<NC, E>(bprime) << LOG2NC) + rho) * SZ)) = v;
@@ -458,7 +495,7 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(E, LOG2L, LOG2TS) team_quad_kernel(TeamParams<T>
             const int g = t & (E - 1), c2 = ap + 4 * (((t >> log2E) & 3) + 4 * (t >> (log2E + 4)));
             const unsigned j2 = (unsigned)(NC * s + c2);  // my column of the transform
             const cpx<T> f1 = wn((unsigned)M * j2), f2 = cmul(f1, f1), f3 = cmul(f2, f1);
-            const cpx<T> base0 = wn((unsigned)g * j2);
+            const cpx<T> base0 = QUAD_CK_FOLD ? cscale(wn((unsigned)g * j2), p.scale) : wn((unsigned)g * j2);
             const cpx<T> sp = wn((unsigned)E * j2);
             FFT_UNROLL
             for (int k = 0; k < E; k++) {
@@ -493,12 +530,15 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(E, LOG2L, LOG2TS) team_quad_kernel(TeamParams<T>
                 FFT_UNROLL
                 for (int k = 0; k < E; k++) blk[r][k] = cmul(blk[r][k], w[k]);
 #endif
-                if (r == 0) send(0);  // drains under block 1's twiddles
+                if (r == 0) {
+                    if (QUAD_SLOTS == 3) wait_all(G);  // slot 0 was last read in the previous transform's round 3
+                    send(0);  // drains under block 1's twiddles
+                }
                 if (r == 1) {
                     // ================= exchange + row step begins: the team learns that my round-0 values are in L2 while I
                     // still twiddle blocks 2 and 3 (the first team wait absorbs the column step's skew: work behind the
                     // arrival is free)
-                    if (QUAD_ARR5) {  // everybody's image of the previous transform's round 3 has landed: long true
+                    if (QUAD_ARR5 && QUAD_SLOTS == 2) {  // everybody's image of the previous transform's round 3 has landed: long true
                         if (QUAD_MERGE) poll_all(G);
                         else wait_all(G);
                     }
@@ -506,7 +546,7 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(E, LOG2L, LOG2TS) team_quad_kernel(TeamParams<T>
                     FFT_SYNC_LDS();
                     arrive();  // arrival G + 1
                     ev();
-                    if (QUAD_ARR5) send(1);  // slot 1 was last read in that round 3
+                    if (QUAD_ARR5) send(1);  // slot 1 was last read in that round 3 (three slots: in the previous transform's round 1)
                 }
             }
         }
@@ -516,6 +556,7 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(E, LOG2L, LOG2TS) team_quad_kernel(TeamParams<T>
         ev();
         dma_window(0, 0);
         if (!QUAD_ARR5) send(1);
+        static_assert(QUAD_SLOTS == 2 || QUAD_ARR5, "three slots need the fifth arrival");
         FFT_UNROLL
         for (int r = 0; r < 4; r++) {
             FFT_WAIT_VM0();  // the round's image has landed and my round-(r + 1) values are in L2 ...
@@ -534,8 +575,9 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(E, LOG2L, LOG2TS) team_quad_kernel(TeamParams<T>
                 // the next round's image is requested NOW (the other image was last read in round r - 1) and flies under this
                 // round's second stage; behind it the values of round r + 2, into the slot this round's image came from
                 ev();
-                dma_window((r + 1) & 1, (r + 1) & 1);
+                dma_window((r + 1) % QUAD_SLOTS, (r + 1) & 1);
                 if (r < 2) send(r + 2);
+                static_assert(!(QUAD_MERGE && QUAD_SLOTS == 3), "three slots: not with QUAD_MERGE");
             }
             FFT_OPAQUE(t);
             const int nr = t >> LOG2NC;
@@ -551,8 +593,17 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(E, LOG2L, LOG2TS) team_quad_kernel(TeamParams<T>
                 // (everybody's image of round r has landed: arrival G + r + 2 says so)
                 wait_all(G + r + 2);
                 ev();
-                dma_window((r + 1) & 1, (r + 1) & 1);
-                if (r < 2) send(r + 2);
+                dma_window((r + 1) % QUAD_SLOTS, (r + 1) & 1);
+                if (QUAD_SLOTS == 3) {
+                    // slot 2 was last read in the previous transform's round 2 (everybody's arrival G says more than that);
+                    // slot 0 takes round 3 once everybody's image of round 0 has landed: arrival G + 2, just waited for
+                    if (r == 0) {
+                        send(2);
+                        send(3);
+                    }
+                } else if (r < 2) {
+                    send(r + 2);
+                }
             }
             dft_inplace<T, E>(v);
             const int apr = (r - sigma) & 3;  // the class this round delivered (workgroup-uniform)
@@ -586,6 +637,38 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(E, LOG2L, LOG2TS) team_quad_kernel(TeamParams<T>
                 cpx<T> y[2][4];
                 FFT_UNROLL
                 for (int h = 0; h < 2; h++) {
+#if QUAD_CK_FOLD
+                    // y[k] = i^(sigma k) * DFT4(u)[k]: with A = u0 + u2, B = u1 + u3, C = u0 - u2, D = u1 - u3 the four cases are the
+                    // same eight additions with operands swapped (sigma is workgroup-uniform: one scalar branch)
+                    const cpx<T> u0 = zt[0][2 * i + h], u1 = zt[1][2 * i + h], u2 = zt[2][2 * i + h], u3 = zt[3][2 * i + h];
+                    const cpx<T> A = cadd(u0, u2), B = cadd(u1, u3);
+                    y[h][0] = cadd(A, B);
+                    if (sigma == 0) {
+                        const cpx<T> C = csub(u0, u2), D = csub(u1, u3);
+                        y[h][2] = csub(A, B);
+                        y[h][1] = cadd_mni(C, D);  // C - i D
+                        y[h][3] = csub_mni(C, D);  // C + i D
+                    } else if (sigma == 1) {
+                        const cpx<T> C = csub(u0, u2), D = csub(u1, u3);
+                        y[h][2] = csub(B, A);
+                        y[h][1] = csub_mni(D, C);  // i (C - i D) = D + i C
+                        y[h][3] = cadd_mni(D, C);  // -i (C + i D) = D - i C
+                    } else if (sigma == 2) {
+                        const cpx<T> Cn = csub(u2, u0), D = csub(u1, u3);
+                        y[h][2] = csub(A, B);
+                        y[h][1] = csub_mni(Cn, D);  // -(C - i D) = -C + i D
+                        y[h][3] = cadd_mni(Cn, D);  // -(C + i D) = -C - i D
+                    } else {
+                        const cpx<T> C = csub(u0, u2), Dn = csub(u3, u1);
+                        y[h][2] = csub(B, A);
+                        y[h][1] = cadd_mni(Dn, C);  // -i (C - i D) = -D - i C
+                        y[h][3] = csub_mni(Dn, C);  // i (C + i D) = -D + i C
+                    }
+                    if (p.inverse) {
+                        FFT_UNROLL
+                        for (int r = 0; r < 4; r++) y[h][r] = cswap(y[h][r]);
+                    }
+#else
                     FFT_UNROLL
                     for (int r = 0; r < 4; r++) y[h][r] = zt[r][2 * i + h];
                     dft_inplace<T, 4>(y[h]);
@@ -594,11 +677,12 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(E, LOG2L, LOG2TS) team_quad_kernel(TeamParams<T>
                         y[h][r] = cmul(y[h][r], ck[r]);
                         if (p.inverse) y[h][r] = cswap(y[h][r]);
                     }
+#endif
                 }
                 FFT_UNROLL
                 for (int ka = 0; ka < 4; ka++) {
                     vec16<T> v;
-                    pair_rows<T>(y[0][ka], y[1][ka], odd, 1, v);
+                    quad_pair<T>(y[0][ka], y[1][ka], odd, v);
                     const long long k2 = nr + E * (2 * i + (odd ? 1 : 0)) + M * ka;
                     vec16<T>* const dst = reinterpret_cast<vec16<T>*>(line0 + (k2 << LOG2L));
                     if (p.nt_mask & 2) FFT_STORE16_NT(dst, v);

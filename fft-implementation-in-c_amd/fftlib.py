@@ -28,7 +28,7 @@ class PlanInfo(C.Structure):
     _fields_ = [("n", C.c_int), ("batch", C.c_int), ("direction", C.c_int), ("precision", C.c_int),
                 ("algo", C.c_int), ("device", C.c_int), ("bluestein_m", C.c_int), ("n_passes", C.c_int),
                 ("factors", C.c_int * 4), ("chunk_batch", C.c_int), ("workspace_bytes", C.c_size_t),
-                ("team_tiles", C.c_int), ("fused", C.c_int)]
+                ("team_tiles", C.c_int), ("fused", C.c_int), ("team_kernel", C.c_int)]
 
 
 # every symbol include/*.h declares, with its ctypes signature

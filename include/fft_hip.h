@@ -89,6 +89,9 @@ typedef struct {
                            ride on the first load / last store of the transforms, 2 and the forward transform's last pass and
                            the inverse's first pass are ONE kernel (2 * n_passes - 1 launches per group of chunk_batch), 3 the padded
                            transform fits one LDS tile and forward transform, product and inverse transform are ONE kernel */
+    int team_kernel;    /* which one-round-trip kernel team_tiles refers to: 0 none, 1 team_fft_kernel (csrc/fft_team.h), 2
+                           team_defer_kernel (csrc/fft_team_defer.h), 3 team_quad_kernel (csrc/fft_team_quad.h: whole-line row
+                           segments, both steps decimated by 4, the exchange in four rounds through the XCD's L2) */
 } fft_gpu_plan_info_t;
 
 /* Per-plan switches (tests and integrators; nothing here changes results) */

@@ -185,6 +185,32 @@ def test_team_kernel(n, batch, dtype, log2seats, n_xcc, threads, lds, tiles, pla
             assert rel(y, oracle(x, d)) < TEAM_TOL[dtype], (n, d, inplace)
 
 
+@pytest.mark.parametrize("batch,n_xcc", [(2, 2), (5, 2), (9, 1), (16, 3)])
+def test_team_quad_kernel(batch, n_xcc, monkeypatch):
+    """team_quad_kernel (fft_team_quad.h) in its emulated shape: n = 4096 = 64 x 64, E = 4 values per thread and chunk, teams of
+    4 seats of 64 threads (NC = 16 columns per seat: the 128-byte-row image with its row-slot swap), every seat in a different
+    row block (all four class rotations), ragged batches, both directions, in place and out of place.  The device shape
+    (n = 2^20, E = 16, teams of 32) is the same source with other constants; tests/test_gpu_parity.py covers it."""
+    monkeypatch.setenv("FFT_EMU_TEAM_QUAD", "1")
+    x = O.gen_lcg(4096, 23, batch).astype(np.complex64)
+    for d in (-1, 1):
+        for inplace in (False, True):
+            y, info = E.emu_fft_team(x, d, log2seats=2, n_xcc=n_xcc, threads=64, lds_budget=8192, inplace=inplace)
+            assert info[0] // 100 == 4 and info[6] & 8, "team_quad_kernel was not planned"
+            assert info[5] == 1, "status / fallback / timeout counters: %d" % info[5]
+            assert rel(y, oracle(x, d)) < TEAM_TOL[np.complex64], (batch, d, inplace)
+
+
+def test_team_quad_kernel_falls_back_when_teams_cannot_form(monkeypatch):
+    """Workgroup 0 reports the wrong XCD: the quad kernel must leave before touching anything (status 1) and the multi-pass
+    plan queued behind it must produce the result."""
+    monkeypatch.setenv("FFT_EMU_TEAM_QUAD", "1")
+    x = O.gen_lcg(4096, 29, 4).astype(np.complex64)
+    y, info = E.emu_fft_team(x, -1, log2seats=2, n_xcc=2, threads=64, lds_budget=8192, skew=True)
+    assert info[6] & 8 and info[5] % 10 == 2, info  # status NO_TEAMS
+    assert rel(y, oracle(x, -1)) < TEAM_TOL[np.complex64]
+
+
 @pytest.mark.parametrize("n,batch,log2seats,n_xcc,threads,lds,l1", [
     (4096, 5, 2, 2, 16, 16384, None),     # 64 x 64, CB = 4: a team of 4; block parity = a bit of the row-in-thread index
     (2048, 9, 2, 2, 16, 8192, None),      # 32 x 64, two teams of 2 per "XCD"
