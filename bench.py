@@ -291,23 +291,61 @@ def main():
                          "clocks and the first few ms-sized steps would otherwise be timed on the ramp (0 = off)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the fp64 2^19 secondary line and the device copy")
     ap.add_argument("--cpu-baseline-only", action="store_true", help="(internal) print the CPU baseline JSON for --workload and exit")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="(tests) launcher rehearsal without a GPU: the ranks meet over gloo, reduce a dummy time and rank 0 prints n_gpus")
     args = ap.parse_args()
     if args.cpu_baseline_only:  # child process of the main run: a crash here (e.g. SIGILL in a comparator) cannot lose the GPU line
         n, batch, dtype, desc = WORKLOADS[args.workload]
         print(json.dumps(cpu_baseline(n, dtype)), flush=True)
         return
 
-    import numpy as np
-    import torch
-    import fftlib
+    # --gpus N without a launcher around us: start the N ranks OURSELVES, as a torch.distributed.run child process, BEFORE
+    # anything in this process imports torch or touches a GPU (a process that has initialised the GPU must never exec or
+    # re-exec; this parent only waits and hands the child's exit code on).  `python bench.py --gpus 8` therefore can never
+    # silently measure one GPU: the ranks below insist on WORLD_SIZE == --gpus and on N visible devices.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node %d (or let bench.py start its own ranks: "
+                         "run it without a launcher)" % (args.gpus, world, args.gpus))
+    if args.dry_run:
+        import torch
+        import torch.distributed as dist_mod
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist_mod.init_process_group(backend="gloo")
+            dist_mod.barrier()
+            t = torch.tensor([1.0 + rank], dtype=torch.float64)
+            dist_mod.all_reduce(t, op=dist_mod.ReduceOp.MAX)
+            assert float(t.item()) == float(world)
+            dist_mod.barrier()
+            dist_mod.destroy_process_group()
+        if rank == 0:
+            b0, b1 = shard_range(world - 1, world, WORKLOADS[args.workload][1])
+            print(json.dumps({"dry_run": True, "n_gpus": world, "gpus_arg": args.gpus, "last_rank_shard": [b0, b1]}), flush=True)
+        return
+
+    import numpy as np
+    import torch
+    import fftlib
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
+    if torch.cuda.device_count() < world or local_rank >= torch.cuda.device_count():
+        raise SystemExit("--gpus %d but only %d device(s) are visible" % (args.gpus, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None

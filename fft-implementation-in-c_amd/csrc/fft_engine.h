@@ -490,7 +490,7 @@ class Pow2Plan {
         // With paired row tiles (PAIR) a result store instruction writes whole 128-byte lines, so the result stream can be
         // non-temporal too (as 64-byte halves it could not: the halves left the L2 one by one, WRITE 8.6 -> 10 GB): +3-5 %
         static const int nt_mask = FFT_EXP_ENV("FFT_HIP_TEAM_NT") ? atoi(FFT_EXP_ENV("FFT_HIP_TEAM_NT")) : -1;
-        tp.nt_mask = nt_mask >= 0 ? nt_mask : (team.quad ? 3 : team.nodefer ? 7 : team.pair ? 3 : 1);
+        tp.nt_mask = nt_mask >= 0 ? nt_mask : (team.quad ? 7 : team.nodefer ? 7 : team.pair ? 3 : 1);
         static const int tune = FFT_EXP_ENV("FFT_HIP_TEAM_TUNE") ? atoi(FFT_EXP_ENV("FFT_HIP_TEAM_TUNE")) : 0;
         tp.tune = tune;
         tp.force_no_teams = team_force_fallback ? 1 : 0;  // test hook (fft_gpu_plan_set_option_hip): exercise the fallback on a healthy device

@@ -481,7 +481,20 @@ int fft_gpu_copy_h2d_bytes_hip(fft_gpu_memory_t dst, const void* src, size_t byt
         fprintf(stderr, "fft_hip: h2d copy of %zu bytes exceeds the %zu-byte buffer\n", bytes, dst->size);
         return -1;
     }
-    HIP_TRY(hipMemcpy(dst->device_ptr, src, bytes, hipMemcpyHostToDevice), return -1);
+    if (hipMemcpy(dst->device_ptr, src, bytes, hipMemcpyHostToDevice) == hipSuccess) return 0;
+    // The runtime rejects a copy that runs past a page-locked range starting at `src` (another plan registered a SHORTER
+    // prefix of this array): go through a bounce buffer of our own instead of failing with stale data on the device.
+    (void)hipGetLastError();
+    void* tmp = malloc(bytes);
+    if (!tmp) return -1;
+    memcpy(tmp, src, bytes);
+    const hipError_t e = hipMemcpy(dst->device_ptr, tmp, bytes, hipMemcpyHostToDevice);
+    free(tmp);
+    if (e != hipSuccess) {
+        fprintf(stderr, "fft_hip: h2d copy of %zu bytes failed: %s\n", bytes, hipGetErrorString(e));
+        (void)hipGetLastError();
+        return -1;
+    }
     return 0;
 }
 
@@ -491,7 +504,18 @@ int fft_gpu_copy_d2h_bytes_hip(void* dst, fft_gpu_memory_t src, size_t bytes) {
         fprintf(stderr, "fft_hip: d2h copy of %zu bytes exceeds the %zu-byte buffer\n", bytes, src->size);
         return -1;
     }
-    HIP_TRY(hipMemcpy(dst, src->device_ptr, bytes, hipMemcpyDeviceToHost), return -1);
+    if (hipMemcpy(dst, src->device_ptr, bytes, hipMemcpyDeviceToHost) == hipSuccess) return 0;
+    (void)hipGetLastError();  // see fft_gpu_copy_h2d_bytes_hip: a shorter page-locked range at `dst`
+    void* tmp = malloc(bytes);
+    if (!tmp) return -1;
+    const hipError_t e = hipMemcpy(tmp, src->device_ptr, bytes, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) memcpy(dst, tmp, bytes);
+    free(tmp);
+    if (e != hipSuccess) {
+        fprintf(stderr, "fft_hip: d2h copy of %zu bytes failed: %s\n", bytes, hipGetErrorString(e));
+        (void)hipGetLastError();
+        return -1;
+    }
     return 0;
 }
 

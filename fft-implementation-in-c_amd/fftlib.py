@@ -90,7 +90,7 @@ SIGNATURES = {
     "fft_export_wisdom_to_string": (_vp, []), "fft_import_wisdom_from_string": (_i, [C.c_char_p]),
     "fft_get_hardware_capabilities": (C.c_uint, []), "fft_plan_with_nthreads": (None, [_i]),
     "fft_alloc_complex": (_vp, [_sz]), "fft_alloc_real": (_vp, [_sz]), "fft_free": (None, [_vp]),
-    "fft_version": (C.c_char_p, []), "fft_plan_measured_algo": (_i, [_vp]), "fft_auto_cleanup": (None, []),
+    "fft_version": (C.c_char_p, []), "fft_plan_measured_algo": (_i, [_vp]), "fft_plan_last_error": (_i, [_vp]), "fft_auto_cleanup": (None, []),
     # include/fft_apps.h, include/fft_utils.h
     "fft_convolution_gpu": (_i, [_vp, _i, _vp, _i, _vp]), "circular_convolution_gpu": (_i, [_vp, _vp, _i, _vp]),
     "compute_periodogram_gpu": (_vp, [_vp, _i, C.c_double]), "autocorrelation_fft_gpu": (_vp, [_vp, _i]),

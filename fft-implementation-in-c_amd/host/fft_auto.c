@@ -53,6 +53,7 @@ struct fft_plan {
     fft_gpu_memory_t gpu_out; /* owned unless == gpu_in */
     int pinned_in, pinned_out; /* the borrowed arrays are page-locked by this plan */
     int measured_algo;         /* FFT_MEASURE: the schedule that won (fft_gpu_algo_t), -1 = not measured */
+    int last_error;            /* run_plan: 0, or the step of the last execute that failed */
 };
 
 static int g_num_threads = 0;
@@ -112,8 +113,13 @@ static int plan_buffers(fft_plan_t plan) {
     plan->gpu_out = (plan->in == plan->out && plan->in_bytes == plan->out_bytes) ? plan->gpu_in : fft_gpu_alloc_bytes_hip(plan->out_bytes);
     if (!plan->gpu_in || !plan->gpu_out) return -1;
     if (!(plan->flags & FFT_CONSERVE_MEMORY)) {
-        plan->pinned_in = fft_gpu_host_register_hip(plan->in, plan->in_bytes) == 0;
-        if (plan->out != plan->in) plan->pinned_out = fft_gpu_host_register_hip(plan->out, plan->out_bytes) == 0;
+        /* in == out (an in-place r2c writes n/2 + 1 complex values over n reals): ONE page-locked range that covers both uses.
+         * A range the runtime already knows (another plan on the same array) is left alone -- the copies then go the pageable
+         * way, through a bounce buffer where the known range is shorter than this plan's (fft_gpu_copy_*_bytes_hip). */
+        const size_t in_reg = (plan->out == plan->in && plan->out_bytes > plan->in_bytes) ? plan->out_bytes : plan->in_bytes;
+        if (!fft_gpu_host_is_registered_hip(plan->in)) plan->pinned_in = fft_gpu_host_register_hip(plan->in, in_reg) == 0;
+        if (plan->out != plan->in && !fft_gpu_host_is_registered_hip(plan->out))
+            plan->pinned_out = fft_gpu_host_register_hip(plan->out, plan->out_bytes) == 0;
     }
     return 0;
 }
@@ -144,16 +150,28 @@ fft_plan_t fft_plan_dft_1d(int n, complex_t* in, complex_t* out, int sign, unsig
 /* which schedule FFT_MEASURE kept (fft_gpu_algo_t), -1 when the plan was not measured (additive) */
 int fft_plan_measured_algo(fft_plan_t plan) { return plan ? plan->measured_algo : -1; }
 
-static void run_plan(fft_plan_t plan, const void* in, void* out) {
-    if (fft_gpu_copy_h2d_bytes_hip(plan->gpu_in, in, plan->in_bytes) != 0) return;
+/* 0, or which step failed (1 copy in, 2 transform, 3 copy out): fft_execute() is void in the reference's API, so the status
+ * is kept on the plan (fft_plan_last_error) and reported on stderr -- never silently dropped */
+static int run_plan(fft_plan_t plan, const void* in, void* out) {
+    plan->last_error = 0;
+    if (fft_gpu_copy_h2d_bytes_hip(plan->gpu_in, in, plan->in_bytes) != 0) plan->last_error = 1;
     /* a plan made for distinct arrays can still be executed in place and vice versa */
-    fft_gpu_execute(plan->gpu_plan, plan->gpu_in, plan->gpu_out);
-    (void)fft_gpu_copy_d2h_bytes_hip(out, plan->gpu_out, plan->out_bytes);
+    if (!plan->last_error) {
+        fft_gpu_execute(plan->gpu_plan, plan->gpu_in, plan->gpu_out);
+        if (fft_gpu_plan_sync_hip(plan->gpu_plan) != 0) plan->last_error = 2;
+    }
+    if (!plan->last_error && fft_gpu_copy_d2h_bytes_hip(out, plan->gpu_out, plan->out_bytes) != 0) plan->last_error = 3;
+    if (plan->last_error)
+        fprintf(stderr, "fft_execute: step %d of copy-in / transform / copy-out failed; the output array was not written\n", plan->last_error);
+    return plan->last_error;
 }
+
+/* status of the plan's last execute: 0 done, 1 / 2 / 3 the copy in / the transform / the copy out failed (additive) */
+int fft_plan_last_error(fft_plan_t plan) { return plan ? plan->last_error : -1; }
 
 void fft_execute(fft_plan_t plan) {
     if (!plan) return;
-    run_plan(plan, plan->in, plan->out);
+    (void)run_plan(plan, plan->in, plan->out);
 }
 
 void fft_execute_dft(fft_plan_t plan, complex_t* in, complex_t* out) {
@@ -162,7 +180,7 @@ void fft_execute_dft(fft_plan_t plan, complex_t* in, complex_t* out) {
         fprintf(stderr, "fft_execute_dft: complex-to-complex plans only\n");
         return;
     }
-    run_plan(plan, in, out);
+    (void)run_plan(plan, in, out);
 }
 
 void fft_destroy_plan(fft_plan_t plan) {

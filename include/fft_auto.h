@@ -62,6 +62,10 @@ fft_plan_t fft_plan_dft_2d(int rows, int cols, complex_t* in, complex_t* out, in
 /* additive: which schedule FFT_MEASURE / FFT_PATIENT / FFT_EXHAUSTIVE kept for a plan (fft_gpu_algo_t of fft_hip.h; -1 =
  * the plan was not measured), and a way to drop the plans fft_auto() keeps between calls */
 int fft_plan_measured_algo(fft_plan_t plan);
+/* additive: fft_execute() / fft_execute_dft() are void (reference fft_auto.h:63-70); the status of a plan's last execute is
+ * kept here: 0 done, 1 the copy to the device failed, 2 the transform failed, 3 the copy back failed (the output array was not
+ * written; a message went to stderr) */
+int fft_plan_last_error(fft_plan_t plan);
 void fft_auto_cleanup(void);
 char* fft_export_wisdom_to_string(void);
 int fft_import_wisdom_from_string(const char* wisdom);

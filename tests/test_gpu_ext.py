@@ -123,6 +123,39 @@ def test_r2c_c2r_host_planner_api(gpu_lib):
     assert lib.fft_plan_r2c_1d(0, x.ctypes.data, X.ctypes.data, 0) is None
 
 
+def test_host_planner_in_place_r2c_and_plans_sharing_an_array(gpu_lib):
+    """(1) an in-place r2c plan (in == out) writes n/2 + 1 complex values = 8 n + 16 bytes over an array it read 8 n
+    bytes from: the page-locked range must cover the larger use; (2) a second, LARGER plan on an array that a smaller plan has
+    already page-locked must still move its whole input and output (bounce buffer), never leave stale output; both report
+    through fft_plan_last_error."""
+    lib = gpu_lib
+    n = 2048
+    buf = np.zeros(n // 2 + 1, dtype=np.complex128)  # room for the in-place result
+    x = lcg((n,), 5, np.complex128).real.copy()
+    buf.view(np.float64)[:n] = x
+    p = lib.fft_plan_r2c_1d(n, buf.ctypes.data, buf.ctypes.data, 0)
+    assert p
+    lib.fft_execute(p)
+    assert lib.fft_plan_last_error(p) == 0
+    lib.fft_destroy_plan(p)
+    assert rel(buf, O.oracle_r2c(x)) < 1e-12
+    # two plans of different length on one scratch array, the small one first (it page-locks the prefix)
+    big = 8192
+    a = lcg((big,), 7, np.complex128)
+    y = np.zeros(big, dtype=np.complex128)
+    small = lib.fft_plan_dft_1d(1024, a.ctypes.data, y.ctypes.data, -1, 0)
+    large = lib.fft_plan_dft_1d(big, a.ctypes.data, y.ctypes.data, -1, 0)
+    assert small and large
+    lib.fft_execute(large)
+    assert lib.fft_plan_last_error(large) == 0
+    assert rel(y, O.oracle_fft(a[None, :], -1, "dit")[0]) < 1e-12
+    lib.fft_execute(small)
+    assert lib.fft_plan_last_error(small) == 0
+    assert rel(y[:1024], O.oracle_fft(a[None, :1024], -1, "dit")[0]) < 1e-12
+    lib.fft_destroy_plan(small)
+    lib.fft_destroy_plan(large)
+
+
 # ------------------------------------------------------------------ f3: fused consumers
 @pytest.mark.parametrize("nx,nh", [(100, 17), (256, 256), (1, 1), (33, 5)])
 def test_convolution_vs_reference_golden(gpu_lib, nx, nh):

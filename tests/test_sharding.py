@@ -80,3 +80,27 @@ def test_shard_range_is_a_partition():
             a, b = shard_range(r, world, 512)
             seen.extend(range(a, b))
         assert seen == list(range(512 * world))
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` WITHOUT a launcher must start two ranks itself (a torch.distributed.run child, before the
+    parent imports torch) and report n_gpus == 2 -- never a silent one-GPU measurement.  --dry-run: the
+    ranks meet over gloo and skip the GPU work, which this container does not have."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    bench = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--dry-run"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["gpus_arg"] == 2 and line["last_rank_shard"] == [512, 1024]
+
+
+def test_bench_refuses_a_world_that_is_not_gpus():
+    import subprocess
+    import sys
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    bench = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--dry-run"], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
