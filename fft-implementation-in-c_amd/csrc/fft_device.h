@@ -252,6 +252,17 @@ __device__ __forceinline__ void fft_store16_sc1(V16* ptr, const V16& v) {
     __builtin_memcpy(&raw, &v, 16);
     asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(ptr), "v"(raw) : "memory");
 }
+// experiments: 16-byte store with arbitrary cache-policy bits (POL: 1 nt, 2 sc0 sc1 nt, 3 sc1 nt, 4 sc0 sc1, 5 sc0 nt)
+template <int POL, class V16>
+__device__ __forceinline__ void fft_store16_pol(V16* ptr, const V16& v) {
+    fft_u32x4 raw;
+    __builtin_memcpy(&raw, &v, 16);
+    if (POL == 2) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(ptr), "v"(raw) : "memory");
+    else if (POL == 3) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(ptr), "v"(raw) : "memory");
+    else if (POL == 4) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(ptr), "v"(raw) : "memory");
+    else if (POL == 5) asm volatile("global_store_dwordx4 %0, %1, off sc0 nt" ::"v"(ptr), "v"(raw) : "memory");
+    else asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(ptr), "v"(raw) : "memory");
+}
 #define FFT_WAIT_VM_LE(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")  // at most n of my memory operations still in flight
 #define FFT_WAVE_LOCKSTEP() ((void)0)
 // One 8-byte LDS access that STAYS one ds_read_b64 / ds_write_b64: hipcc otherwise fuses pairs of them into ds_read2_b64 /
@@ -272,6 +283,15 @@ __device__ __forceinline__ void fft_dma16(const void* gsrc, unsigned lane_lds_ad
                      : "=&s"(saved_m0) : "v"(gsrc), "s"(lds_addr) : "memory");
     else if (SC1 == 2)
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                     : "=&s"(saved_m0) : "v"(gsrc), "s"(lds_addr) : "memory");
+    else if (SC1 == 4)  // system scope
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off sc0 sc1\n\ts_mov_b32 m0, %0"
+                     : "=&s"(saved_m0) : "v"(gsrc), "s"(lds_addr) : "memory");
+    else if (SC1 == 5)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off sc0 sc1 nt\n\ts_mov_b32 m0, %0"
+                     : "=&s"(saved_m0) : "v"(gsrc), "s"(lds_addr) : "memory");
+    else if (SC1 == 6)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off sc0 nt\n\ts_mov_b32 m0, %0"
                      : "=&s"(saved_m0) : "v"(gsrc), "s"(lds_addr) : "memory");
     else if (SC1 == 3)  // served by the shared L2, and the line is the first to leave it afterwards (read once)
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off sc1 nt\n\ts_mov_b32 m0, %0"

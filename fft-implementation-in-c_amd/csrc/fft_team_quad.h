@@ -73,6 +73,12 @@
 #ifndef QUAD_SLOTS       // window slots per team: 2, or 3 (round r in slot r mod 3: every round's values are in L2 a round earlier; the
 #define QUAD_SLOTS 2     // window is 6 MiB per XCD instead of 4).  The planner allocates 3.
 #endif
+#ifndef QUAD_LOAD_POL    // experiments: cache-policy bits of the column DMA: 2 nt (default), 4 sc0 sc1, 5 sc0 sc1 nt, 6 sc0 nt
+#define QUAD_LOAD_POL 2
+#endif
+#ifndef QUAD_STORE_POL   // experiments: cache-policy bits of the result stores: 1 nt (default), 2 sc0 sc1 nt, 3 sc1 nt, 4 sc0 sc1, 5 sc0 nt
+#define QUAD_STORE_POL 1
+#endif
 #ifndef QUAD_FINE_TRACE  // profiling builds only: time stamps inside the chunks of transform 3 (tools/quad_fine.py)
 #define QUAD_FINE_TRACE 0
 #endif
@@ -340,7 +346,13 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(E, LOG2L, LOG2TS) team_quad_kernel(TeamParams<T>
         const unsigned lds = img_lds0 + (unsigned)im * IMG;
         if (p.nt_mask & 1) {
             FFT_UNROLL
-            for (int i = 0; i < NCH; i++) FFT_DMA16_NT(src + i * step, img_b[im], lds, (unsigned)(i * NTHR + tid) * 16u);
+            for (int i = 0; i < NCH; i++) {
+#if defined(FFT_EMU)
+                FFT_DMA16_NT(src + i * step, img_b[im], lds, (unsigned)(i * NTHR + tid) * 16u);
+#else
+                fft_dma16<QUAD_LOAD_POL>(src + i * step, lds + (unsigned)(i * NTHR + tid) * 16u);
+#endif
+            }
         } else {
             FFT_UNROLL
             for (int i = 0; i < NCH; i++) FFT_DMA16(src + i * step, img_b[im], lds, (unsigned)(i * NTHR + tid) * 16u);
@@ -685,8 +697,12 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(E, LOG2L, LOG2TS) team_quad_kernel(TeamParams<T>
                     quad_pair<T>(y[0][ka], y[1][ka], odd, v);
                     const long long k2 = nr + E * (2 * i + (odd ? 1 : 0)) + M * ka;
                     vec16<T>* const dst = reinterpret_cast<vec16<T>*>(line0 + (k2 << LOG2L));
-                    if (p.nt_mask & 2) FFT_STORE16_NT(dst, v);
+#if defined(FFT_EMU)
+                    *dst = v;
+#else
+                    if (p.nt_mask & 2) fft_store16_pol<QUAD_STORE_POL>(dst, v);
                     else *dst = v;
+#endif
                 }
             }
         }
