@@ -217,29 +217,31 @@ class Pow2Plan {
     // ---- team_quad_kernel (fft_team_quad.h): n = L x L with L = 4 E^2, teams of TS = n / (4 tiles) seats.  Built for fp32
     // n = 2^20 on the device (E = 16, a whole XCD per transform) and for n = 2^12 in the emulation (E = 4, 64-thread
     // workgroups, teams of 4).  Tables [W_n^x, x < L | W_L^y, y < L]; window: 2 slots of TS images per team.
-    static constexpr int quad_E(int log2n_) { return log2n_ == 20 ? 16 : log2n_ == 12 ? 4 : 0; }
+    // ---- team_quad_kernel (fft_team_quad.h): n = L x L, L = 4 M, M = E R2 (E values per thread and chunk, a radix-E and a radix-R2
+    // stage), teams of TS = L R2 / threads seats.  Device (512 threads, E = 16): n = 2^20 (R2 16, teams of 32), 2^18 (R2 8, teams of
+    // 8), 2^16 (R2 4, teams of 2); emulation (E = 4): n = 2^12 (R2 4) and 2^10 (R2 2).  Tables [W_n^x, x < L/2 | W_L^y, y < L |
+    // W_n^(L/2)]; window: 2 slots of TS images per team.
+    static constexpr int quad_E(int log2n_) { return (log2n_ == 20 || log2n_ == 18 || log2n_ == 16) ? 16 : (log2n_ == 12 || log2n_ == 10) ? 4 : 0; }
     void build_team_quad(int batch) {
         const int mode = rt->policy.team_mode;
         if (mode <= 0 || SZ != 8 || (log2n & 1)) return;
         const int E = quad_E(log2n);
-        // 0: no; 1: one 512-thread workgroup per CU (teams of 32 at n = 2^20); 2: TWO 256-thread workgroups per CU (teams of
-        // 64, 128-byte row segments): the two run out of step, one's arithmetic fills the other's LDS and barrier waits
-        const int variant = E ? rt->team_quad(SZ, log2n) : 0;
-        if (!variant) return;
+        if (!E || !rt->team_quad(SZ, log2n)) return;
         TeamDesc<T> d;
         if (!rt->team_geometry(d.log2seats, d.n_xcc, d.nthreads)) return;
-        if (variant == 2) { d.log2seats += 1; d.nthreads /= 2; }
         const int log2L = log2n / 2;
         const long long L = 1ll << log2L;
-        if (L != 4ll * E * E) return;
-        const int log2TE = ilog2(d.nthreads) + ilog2(E);  // values of a chunk image
+        const long long R2 = L / 4 / E;
+        if (R2 < 2 || R2 > E || R2 * E * 4 != L) return;
+        const int log2TE = log2L - 2 + ilog2(d.nthreads) - ilog2(R2);  // values of a chunk image: M rows x (threads / R2) columns
         d.log2TS = log2n - 2 - log2TE;
-        if (d.log2TS < 2 || d.log2TS > d.log2seats) return;
-        if ((L >> d.log2TS) * E != d.nthreads || (L >> d.log2TS) < 16) return;
+        if (d.log2TS < 1 || d.log2TS > d.log2seats) return;
+        const long long NC = L >> d.log2TS;
+        if (NC * R2 != d.nthreads || NC < 8 || NC > 2 * (L / 4)) return;
 #if !defined(FFT_EMU)
-        if (!(log2n == 20 && (d.log2TS == 5 || d.log2TS == 6))) return;  // the device instantiations
+        if (!((log2n == 20 && d.log2TS == 5) || (log2n == 18 && d.log2TS == 3) || (log2n == 16 && d.log2TS == 1))) return;  // the device instantiations
 #else
-        if (!(log2n == 12 && d.log2TS == 2)) return;  // the emulation's instantiation
+        if (!((log2n == 12 && d.log2TS == 2) || (log2n == 10 && (d.log2TS == 1 || d.log2TS == 2)))) return;  // the emulation's
 #endif
         if (mode == 1 && !rt->team_default_on(SZ, log2n)) return;
         d.quad = true;
@@ -251,7 +253,7 @@ class Pow2Plan {
         d.data_bytes = 2 * (SZ << log2TE);
         d.tables_elems = (int)(L / 2 + L);  // what the kernel keeps in LDS: [W_n^x, x < L/2 | W_L^y, y < L]; W_n^(L/2) follows in the blob
         d.smem_bytes = d.data_bytes + d.tables_elems * SZ + 16;
-        if (d.smem_bytes * (variant == 2 ? 2 : 1) > rt->max_lds_bytes()) return;
+        if (d.smem_bytes > rt->max_lds_bytes()) return;
         std::vector<cpx<T>> blob, part;
         make_twiddle_table<T>(blob, L * L, L / 2, 1);
         make_twiddle_table<T>(part, L, L, 1);
@@ -259,7 +261,7 @@ class Pow2Plan {
         make_twiddle_table<T>(part, L * L, 2, L / 2);
         blob.push_back(part[1]);
         blob.push_back(part[0]);  // (pad to 16 bytes)
-        d.scratch_bytes = ((size_t)SZ << (log2TE + d.log2TS)) * 3 * (size_t)d.n_teams;  // three window slots per team (the kernel uses two by default)
+        d.scratch_bytes = ((size_t)SZ << (log2TE + d.log2TS)) * 2 * (size_t)d.n_teams;  // two window slots per team
         d.tables = (cpx<T>*)rt->dmalloc(blob.size() * SZ);
         d.scratch = (unsigned char*)rt->dmalloc(d.scratch_bytes);
         d.sticky = (unsigned*)rt->dmalloc((fftk::TEAM_STICKY_WORDS + fftk::TEAM_CTL_WORDS) * sizeof(unsigned));
@@ -270,7 +272,11 @@ class Pow2Plan {
         }
         rt->memset_async(d.sticky, 0, fftk::TEAM_STICKY_WORDS * sizeof(unsigned));
         rt->h2d(d.tables, blob.data(), blob.size() * SZ);
-        d.min_batch = mode == 1 ? (int)std::max<long long>(4ll * d.n_teams, (256ll << 20) / ((long long)SZ << log2n)) : d.n_teams;
+        // (the batch crossover of the tile-by-tile team kernels, profiles/r2_batch_crossover.txt, until re-measured for this one)
+        {
+            const long long mib = d.log2TS >= 5 ? 256 : d.log2TS == 3 ? 1024 : 2048;
+            d.min_batch = mode == 1 ? (int)std::max<long long>(4ll * d.n_teams, (mib << 20) / ((long long)SZ << log2n)) : d.n_teams;
+        }
         if (rt->policy.team_min_batch > 0) d.min_batch = rt->policy.team_min_batch;
         (void)batch;
         d.ok = true;
@@ -281,10 +287,13 @@ class Pow2Plan {
         const long long grid = (long long)team.n_xcc << team.log2seats;
         if constexpr (SZ == 8) {
 #if defined(FFT_EMU)
-            rt->launch_coresident(fftk::team_quad_kernel<T, 4, 6, 2>, grid, team.nthreads, (size_t)team.smem_bytes, tp);
+            if (log2n == 12) rt->launch_coresident(fftk::team_quad_kernel<T, 4, 2, 6, 2>, grid, team.nthreads, (size_t)team.smem_bytes, tp);
+            else if (team.log2TS == 1) rt->launch_coresident(fftk::team_quad_kernel<T, 4, 1, 5, 1>, grid, team.nthreads, (size_t)team.smem_bytes, tp);
+            else rt->launch_coresident(fftk::team_quad_kernel<T, 4, 1, 5, 2>, grid, team.nthreads, (size_t)team.smem_bytes, tp);
 #else
-            if (team.log2TS == 6) rt->launch_coresident(fftk::team_quad_kernel<T, 16, 10, 6>, grid, team.nthreads, (size_t)team.smem_bytes, tp);
-            else rt->launch_coresident(fftk::team_quad_kernel<T, 16, 10, 5>, grid, team.nthreads, (size_t)team.smem_bytes, tp);
+            if (log2n == 20) rt->launch_coresident(fftk::team_quad_kernel<T, 16, 4, 10, 5>, grid, team.nthreads, (size_t)team.smem_bytes, tp);
+            else if (log2n == 18) rt->launch_coresident(fftk::team_quad_kernel<T, 16, 3, 9, 3>, grid, team.nthreads, (size_t)team.smem_bytes, tp);
+            else rt->launch_coresident(fftk::team_quad_kernel<T, 16, 2, 8, 1>, grid, team.nthreads, (size_t)team.smem_bytes, tp);
 #endif
         }
         (void)grid;

@@ -157,10 +157,13 @@ struct HipRT {
     }
     // team_quad_kernel (fft_team_quad.h) instead of the tile-by-tile team kernels: fp32 n = 2^20.  FFT_HIP_TEAM_QUAD=0 (the
     // experiments build) runs team_defer_kernel.
-    // 1: one 512-thread workgroup per CU; 2: two 256-thread workgroups per CU (teams of 64 seats)
-    int team_quad(int elem_bytes, int log2n) {
+    // team_quad_kernel (fft_team_quad.h) instead of the tile-by-tile team kernels: fp32 n = 2^20, 2^18, 2^16.  FFT_HIP_TEAM_QUAD (the
+    // experiments build): 0 never, 1 every built size (default), or a bit mask 2 = only 2^20, 4 = only 2^18, 8 = only 2^16
+    bool team_quad(int elem_bytes, int log2n) {
         static const int on = FFT_EXP_ENV("FFT_HIP_TEAM_QUAD") ? atoi(FFT_EXP_ENV("FFT_HIP_TEAM_QUAD")) : 1;
-        return (elem_bytes == 8 && log2n == 20) ? on : 0;
+        if (elem_bytes != 8 || !(log2n == 20 || log2n == 18 || log2n == 16)) return false;
+        if (on <= 1) return on == 1;
+        return (on & (log2n == 20 ? 2 : log2n == 18 ? 4 : 8)) != 0;
     }
     bool team_alll2(int, int) {
         static const int on = FFT_EXP_ENV("FFT_HIP_TEAM_ALLL2") ? atoi(FFT_EXP_ENV("FFT_HIP_TEAM_ALLL2")) : 0;

@@ -1,7 +1,9 @@
-// fft_team_quad.hip -- the device instantiation of team_quad_kernel (fft_team_quad.h): fp32 n = 2^20, E = 16, teams of 32.
+// fft_team_quad.hip -- the device instantiations of team_quad_kernel (fft_team_quad.h): fp32, E = 16 values per thread and chunk,
+// 512-thread workgroups, one per CU.
 #include "fft_team_quad.h"
 
 namespace fftk {
-template __global__ void team_quad_kernel<float, 16, 10, 5>(TeamParams<float>);  // one 512-thread workgroup per CU, teams of 32
-template __global__ void team_quad_kernel<float, 16, 10, 6>(TeamParams<float>);  // two 256-thread workgroups per CU, teams of 64
+template __global__ void team_quad_kernel<float, 16, 4, 10, 5>(TeamParams<float>);  // n = 2^20: 1024 x 1024, teams of 32 (a whole XCD)
+template __global__ void team_quad_kernel<float, 16, 3, 9, 3>(TeamParams<float>);   // n = 2^18: 512 x 512, teams of 8
+template __global__ void team_quad_kernel<float, 16, 2, 8, 1>(TeamParams<float>);    // n = 2^16: 256 x 256, teams of 2
 }

@@ -185,20 +185,31 @@ def test_team_kernel(n, batch, dtype, log2seats, n_xcc, threads, lds, tiles, pla
             assert rel(y, oracle(x, d)) < TEAM_TOL[dtype], (n, d, inplace)
 
 
-@pytest.mark.parametrize("batch,n_xcc", [(2, 2), (5, 2), (9, 1), (16, 3)])
-def test_team_quad_kernel(batch, n_xcc, monkeypatch):
-    """team_quad_kernel (fft_team_quad.h) in its emulated shape: n = 4096 = 64 x 64, E = 4 values per thread and chunk, teams of
-    4 seats of 64 threads (NC = 16 columns per seat: the 128-byte-row image with its row-slot swap), every seat in a different
-    row block (all four class rotations), ragged batches, both directions, in place and out of place.  The device shape
-    (n = 2^20, E = 16, teams of 32) is the same source with other constants; tests/test_gpu_parity.py covers it."""
+QUAD_CASES = [  # n, batch, log2seats, "XCDs", threads, LDS bytes
+    (4096, 2, 2, 2, 64, 8192),    # E = 4, M = 4 x 4, teams of 4 seats of 64 threads (NC = 16): every seat in a row block of its own
+    (4096, 9, 2, 1, 64, 8192),    # ragged batch on one "XCD"
+    (4096, 16, 2, 3, 64, 8192),
+    (1024, 5, 1, 2, 32, 4096),    # M = 4 x 2 (two radix-2 butterflies per thread in stage 2), teams of TWO: a seat's rows span two row blocks
+    (1024, 7, 2, 2, 16, 2048),    # the same transform on teams of 4 (NC = 8: two columns per class)
+    (1024, 4, 2, 1, 32, 4096),    # two teams of 2 on one "XCD"
+]
+
+
+@pytest.mark.parametrize("n,batch,log2seats,n_xcc,threads,lds", QUAD_CASES)
+def test_team_quad_kernel(n, batch, log2seats, n_xcc, threads, lds, monkeypatch):
+    """team_quad_kernel (fft_team_quad.h) in its emulated shapes: E = 4 values per thread and chunk, the length-L/4 transforms as
+    4 x 4 (the device's n = 2^20 is 16 x 16) and as 4 x 2 (the device's 16 x 8 at 2^18 and 16 x 4 at 2^16: several radix-R2
+    butterflies per thread in stage 2, adjacent rows in ONE thread at the hand-over), teams of 4 and of 2 seats, ragged batches,
+    both directions, in place and out of place.  The device shapes are the same source with other constants;
+    tests/test_gpu_parity.py covers them."""
     monkeypatch.setenv("FFT_EMU_TEAM_QUAD", "1")
-    x = O.gen_lcg(4096, 23, batch).astype(np.complex64)
+    x = O.gen_lcg(n, 23, batch).astype(np.complex64)
     for d in (-1, 1):
         for inplace in (False, True):
-            y, info = E.emu_fft_team(x, d, log2seats=2, n_xcc=n_xcc, threads=64, lds_budget=8192, inplace=inplace)
+            y, info = E.emu_fft_team(x, d, log2seats=log2seats, n_xcc=n_xcc, threads=threads, lds_budget=lds, inplace=inplace)
             assert info[0] // 100 == 4 and info[6] & 8, "team_quad_kernel was not planned"
             assert info[5] == 1, "status / fallback / timeout counters: %d" % info[5]
-            assert rel(y, oracle(x, d)) < TEAM_TOL[np.complex64], (batch, d, inplace)
+            assert rel(y, oracle(x, d)) < TEAM_TOL[np.complex64], (n, batch, d, inplace)
 
 
 def test_team_quad_kernel_falls_back_when_teams_cannot_form(monkeypatch):
