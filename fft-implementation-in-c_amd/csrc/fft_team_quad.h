@@ -76,6 +76,14 @@ struct QuadShape {
 // spreads them (per half wave the positions 4 il + (g & 3) + (128 / R2) (g >> 2) are 32 different 8-byte slots).
 template <int R2>
 FFT_DEVICE int quad_phi(int g) { return (g & 3) + (128 / R2) * (g >> 2); }
+// ... WITHIN windows of 64 columns: stage 1 rewrites a row in place, and what makes that safe without a barrier is that the
+// lanes that read a window are the lanes of ONE wave (natural map: 64 consecutive columns of one row).  A sender group's columns
+// (one class, ILN of them, 4 apart) lie inside one window, so the spread over the banks is the same.
+template <int R2, int W>
+FFT_DEVICE int quad_rot(int c, int g) {
+    constexpr int RW = W < 64 ? W : 64;
+    return (c & ~(RW - 1)) | ((c + quad_phi<R2>(g)) & (RW - 1));
+}
 
 // w[e] = base * step^e, e < K: K - 1 products at most log2 K deep
 template <typename T, int K>
@@ -150,7 +158,7 @@ FFT_DEVICE void quad_stage1(cpx<T>* img, const cpx<T>* wl, int col, int r, bool 
     mark(0);
     if (ROT) FFT_WAVE_LOCKSTEP();  // the rotated positions were read by other lanes of this wave
     FFT_UNROLL
-    for (int k = 0; k < E; k++) QUAD_ST(&img[((r + R2 * k) << LOG2W) + (ROT ? ((col + quad_phi<R2>(k / G2)) & (W - 1)) : col)], x[k]);
+    for (int k = 0; k < E; k++) QUAD_ST(&img[((r + R2 * k) << LOG2W) + (ROT ? quad_rot<R2, W>(col, k / G2) : col)], x[k]);
 }
 
 // Stage 2, the reads: thread g < R2 of column `col` takes the E values of rows E g + rr, i.e. for each of its G2 = E / R2
@@ -363,7 +371,7 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2R2, LOG2L, LOG2TS) team_quad_kernel(TeamPara
             fine(0);  // 5: B2 passed
             FFT_OPAQUE(t);
             const int g = t & (R2 - 1), c2 = ap + 4 * sender_cc(t);
-            quad_stage2_read<T, E, LOG2NC>(v, img, (c2 + quad_phi<R2>(g)) & (NC - 1), g);
+            quad_stage2_read<T, E, LOG2NC>(v, img, quad_rot<R2, NC>(c2, g), g);
             fine(1);  // 6: stage-2 reads landed
             quad_stage2_dft<T, E, R2>(v);
             fine(0);  // 7: dft
@@ -372,7 +380,7 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2R2, LOG2L, LOG2TS) team_quad_kernel(TeamPara
             FFT_SYNC_LDS();
             FFT_OPAQUE(t);
             const int g = t & (R2 - 1), c2 = ap + 4 * sender_cc(t);
-            quad_stage2_read<T, E, LOG2NC>(v, img, (c2 + quad_phi<R2>(g)) & (NC - 1), g);
+            quad_stage2_read<T, E, LOG2NC>(v, img, quad_rot<R2, NC>(c2, g), g);
             quad_stage2_dft<T, E, R2>(v);
 #endif
             if (a == 0) {
