@@ -189,6 +189,12 @@ class Pow2Plan {
     TeamDesc<T> team;           // team.ok: execute() runs the team kernel, with the two-pass plan queued behind it as fallback
     const unsigned* run_if = nullptr;  // handed to the tile launches of the current execute (fallback mode)
     int team_pending = 0;        // team launches since the host last read the status word
+    // what those launches were asked to do: replayed on the multi-pass schedule if one of them ends in TEAM_STATUS_TIMEOUT
+    // (recover_after_timeout).  An in-place execute cannot be replayed (a broken team has overwritten part of its input).
+    struct TeamExec { const cpx<T>* in; cpx<T>* out; int nb; bool inverse; bool scale_inverse; };
+    std::vector<TeamExec> team_log;
+    bool team_disabled = false;  // a team wait timed out once: the team kernel is never enabled again for this plan
+    int team_unrecoverable = 0;  // in-place executes among the ones a timeout invalidated (since the last recover_after_timeout)
     int team_fallbacks = 0;      // consecutive executes that ended in the two-pass fallback
     int team_last_status = -1;   // what the host last read from the status word (-1: never launched)
     bool team_force_fallback = false;  // test hook: the team kernel pretends its placement check failed
@@ -1350,6 +1356,28 @@ class Pow2Plan {
     }
 
     // Transform `nb` contiguous transforms (nb <= max_batch); in == out allowed.
+    // The host has synchronized and read the team kernel's status (HIP: team_status_of; the emulation: its test driver).
+    // ok: forget the log.  TIMEOUT: a formed team stopped making progress (the kernel's waits are bounded, the launch has
+    // ended) -- its results are invalid.  The team kernel is switched off for this plan and every logged OUT-OF-PLACE execute
+    // since the last sync is replayed on the multi-pass schedule (the inputs are intact); returns the number of executes that
+    // could NOT be repaired (in place: part of the input is gone).  The caller synchronizes again afterwards.
+    int recover_after_timeout(bool timed_out) {
+        int lost = 0;
+        if (timed_out) {
+            team.ok = false;  // (the buffers stay allocated until the plan is destroyed)
+            team_disabled = true;
+            std::vector<TeamExec> log;
+            log.swap(team_log);
+            for (const TeamExec& e : log) {
+                if ((const void*)e.in == (const void*)e.out) { lost++; continue; }
+                execute(e.in, e.out, e.nb, e.inverse, e.scale_inverse);
+            }
+            team_unrecoverable += lost;
+        }
+        team_log.clear();
+        return lost;
+    }
+
     void execute(const cpx<T>* in, cpx<T>* out, int nb, bool inverse, bool scale_inverse = true) {
         const long long n = 1ll << log2n;
         const T scale = (inverse && scale_inverse) ? (T)(1.0L / (long double)n) : (T)1;
@@ -1391,6 +1419,7 @@ class Pow2Plan {
         if (team.ok && nb >= team.min_batch) {
             launch_team(in, out, nb, inverse, scale);
             team_pending++;
+            if (team_log.size() < 4096) team_log.push_back(TeamExec{in, out, nb, inverse, scale_inverse});
             rt->mark(0);
             run_if = team.ctl + fftk::TEAM_CTL_STATUS;
             mark0 = 1;

@@ -322,9 +322,17 @@ int team_status_of(Core* core) {
     if (sticky[0] || sticky[1]) (void)hipMemset(core->team.sticky, 0, sizeof(sticky));
     core->team_last_status = (int)st;
     if (st == fftk::TEAM_STATUS_TIMEOUT) {
-        fprintf(stderr, "fft_hip: a team kernel barrier timed out -- results since the last sync are invalid; this plan "
-                        "continues with the multi-pass schedule\n");
-        core->team.ok = false;  // the buffers stay allocated until the plan is destroyed
+        // the launch has ended (every wait in the kernel is bounded): replay what it was asked to do on the multi-pass schedule
+        const int lost = core->recover_after_timeout(true);
+        if (hipStreamSynchronize(core->rt->stream) != hipSuccess) (void)hipGetLastError();
+        if (lost)
+            fprintf(stderr, "fft_hip: a team kernel barrier timed out; %d in-place execute(s) since the last sync could not be repeated "
+                            "(their input is gone) and hold invalid data; this plan continues with the multi-pass schedule\n", lost);
+        else
+            fprintf(stderr, "fft_hip: a team kernel barrier timed out; the executes since the last sync were repeated on the multi-pass "
+                            "schedule, which this plan keeps from now on\n");
+        if (!lost) st = fftk::TEAM_STATUS_NO_TEAMS;  // the caller sees "done by the fallback"
+        core->team_last_status = (int)st;
     } else if ((int)sticky[fftk::TEAM_STICKY_FALLBACKS] >= launches && launches > 0) {  // every launch fell back
         core->team_fallbacks += launches;
         if (core->team_fallbacks >= 3) {
@@ -335,6 +343,7 @@ int team_status_of(Core* core) {
     } else {
         core->team_fallbacks = 0;
     }
+    if (st != fftk::TEAM_STATUS_TIMEOUT) core->team_log.clear();
     return (int)st;
 }
 
@@ -888,9 +897,11 @@ int fft_gpu_plan_measure_hip(fft_gpu_plan_t p, int iters) {
         if (!buf) return -1;
         (void)hipMemsetAsync(buf, 0, in_b, p->rt.stream);
         const int saved_min = core->team.min_batch;
+        const bool saved_ok = core->team.ok;  // false: switched off before (three fallbacks in a row, an option, a timeout)
         float ms[2] = {0.f, 0.f};
         int rc = 0;
         for (int which = 0; which < 2 && rc == 0; which++) {  // 0 multi-pass, 1 team kernel
+            if (which == 1 && core->team_disabled) { ms[1] = 1e30f; break; }  // a timeout retired the team kernel for good
             core->team.ok = which == 1;
             core->team.min_batch = 1;
             float warm = 0.f;
@@ -900,10 +911,10 @@ int fft_gpu_plan_measure_hip(fft_gpu_plan_t p, int iters) {
         core->team.min_batch = saved_min;
         p->rt.dfree(buf);
         if (rc != 0) {
-            core->team.ok = true;
+            core->team.ok = saved_ok && !core->team_disabled;  // (never re-enable what was off before the call)
             return -1;
         }
-        const bool team_wins = ms[1] < ms[0];
+        const bool team_wins = ms[1] < ms[0] && !core->team_disabled;
         core->team.ok = team_wins;
         if (team_wins) core->team.min_batch = 1;  // measured for this plan's batch: the static crossover no longer applies
         return team_wins ? 1 : 0;
@@ -926,7 +937,7 @@ int fft_gpu_plan_set_option_hip(fft_gpu_plan_t p, fft_gpu_plan_option_t option, 
             each_core([&](auto* c) { c->team_force_fallback = value != 0; });
             return 0;
         case FFT_GPU_OPT_TEAM_ENABLE:
-            each_core([&](auto* c) { c->team.ok = value != 0 && c->team.tables != nullptr; });
+            each_core([&](auto* c) { c->team.ok = value != 0 && c->team.tables != nullptr && !c->team_disabled; });
             return 0;
         case FFT_GPU_OPT_NO_FUSION:
             if (p->b32) p->b32->no_fusion = value != 0;

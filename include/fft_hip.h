@@ -158,6 +158,12 @@ int fft_gpu_plan_info_hip(fft_gpu_plan_t plan, fft_gpu_plan_info_t* info);
  * has the handle 0 -- names it explicitly: (void*)1 = hipStreamLegacy, or its work and the plan's are not ordered. */
 int fft_gpu_plan_set_stream_hip(fft_gpu_plan_t plan, void* hip_stream);
 int fft_gpu_execute_ptr_hip(fft_gpu_plan_t plan, const void* d_in, void* d_out); /* async on the plan's stream */
+/* Waits for the plan's stream.  0: every execute since the last sync holds valid results.  Should a team kernel's bounded wait
+ * have run out (a member of a formed team stopped making progress: a hardware fault, not load -- formation under load falls back
+ * BEFORE anything is touched), the team kernel is retired for this plan and every OUT-OF-PLACE execute since the last sync is
+ * repeated on the multi-pass schedule before this returns (still 0).  -1: the stream failed, or such a timeout hit an IN-PLACE
+ * execute -- its input is partly overwritten, the data is invalid and stderr says so.  (fft_gpu_execute() of fft_gpu.h is void, as in
+ * the reference: gpu/fft_cuda.cu:166-185; callers that need the status of in-place team executes sync through this function.) */
 int fft_gpu_plan_sync_hip(fft_gpu_plan_t plan);
 int fft_gpu_plan_set_option_hip(fft_gpu_plan_t plan, fft_gpu_plan_option_t option, int value);
 /* planner policy for plans created after the call; a negative argument keeps the current value.  team_mode: 0 never

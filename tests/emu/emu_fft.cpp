@@ -126,6 +126,13 @@ static int run(const void* in, void* out, int n, int batch, int dir, int algo, i
             info[6] = plan.team.ok ? (plan.team.asplit ? 1 : 0) + (plan.team.defer ? 2 : 0) + (plan.team.pair ? 4 : 0) + (plan.team.quad ? 8 : 0) : 0;
         }
         plan.execute((const C*)in, (C*)out, batch, dir > 0);
+        if (plan.team.ctl && getenv("FFT_EMU_RECOVER")) {
+            // what the HIP backend does when it synchronizes (team_status_of): a timed-out team kernel's executes are
+            // replayed on the multi-pass schedule; info[3] = executes that could not be (in place)
+            const bool timed_out = plan.team.sticky[fftk::TEAM_STICKY_TIMEOUTS] != 0;
+            const int lost = plan.recover_after_timeout(timed_out);
+            if (info) info[3] = 1000 + lost + (timed_out ? 100 : 0);
+        }
         if (info && plan.team.ctl) {  // what the team kernel reported (the emulation's memory is the host's)
             info[5] = 1 + (int)plan.team.ctl[fftk::TEAM_CTL_STATUS] + 10 * (int)plan.team.sticky[fftk::TEAM_STICKY_FALLBACKS] +
                       100 * (int)plan.team.sticky[fftk::TEAM_STICKY_TIMEOUTS];

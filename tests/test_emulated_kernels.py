@@ -212,6 +212,29 @@ def test_team_quad_kernel(n, batch, log2seats, n_xcc, threads, lds, monkeypatch)
             assert rel(y, oracle(x, d)) < TEAM_TOL[np.complex64], (n, batch, d, inplace)
 
 
+@pytest.mark.parametrize("quad", [False, True])
+def test_team_kernel_timeout_is_repaired_on_the_multi_pass_schedule(quad, monkeypatch):
+    """VERDICT r2 item 6.  A member of a formed team never arrives (FFT_EMU_DROP_BLOCK leaves right after formation): the team's
+    waits run into their bound, the kernel reports TIMEOUT and ends.  What the host does next (HIP: team_status_of inside
+    fft_gpu_plan_sync; here FFT_EMU_RECOVER): the out-of-place execute is REPEATED on the multi-pass schedule and the result is
+    correct; an in-place execute cannot be repeated (its input is partly overwritten) and is reported as lost."""
+    monkeypatch.setenv("FFT_EMU_DROP_BLOCK", "1")
+    monkeypatch.setenv("FFT_EMU_TEAM_TIMEOUT_MS", "300")
+    monkeypatch.setenv("FFT_EMU_RECOVER", "1")
+    if quad:
+        monkeypatch.setenv("FFT_EMU_TEAM_QUAD", "1")
+        geo = dict(log2seats=2, n_xcc=2, threads=64, lds_budget=8192)
+    else:
+        geo = dict(log2seats=2, n_xcc=2, threads=16, lds_budget=16384)
+    x = O.gen_lcg(4096, 31, 6).astype(np.complex64)
+    y, info = E.emu_fft_team(x, -1, **geo)
+    assert info[0] // 100 == 4 and bool(info[6] & 8) == quad
+    assert info[3] == 1100, "timeout seen, nothing lost: %d" % info[3]
+    assert rel(y, oracle(x, -1)) < TEAM_TOL[np.complex64]
+    y, info = E.emu_fft_team(x, -1, inplace=True, **geo)
+    assert info[3] == 1101, "timeout seen, the in-place execute is reported as lost: %d" % info[3]
+
+
 def test_team_quad_kernel_falls_back_when_teams_cannot_form(monkeypatch):
     """Workgroup 0 reports the wrong XCD: the quad kernel must leave before touching anything (status 1) and the multi-pass
     plan queued behind it must produce the result."""
