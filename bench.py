@@ -253,7 +253,8 @@ def kernel_source_hash():
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "fft-implementation-in-c_amd", "csrc")
-    for f in ("fft_device.h", "fft_codelets.h", "fft_kernels.h", "fft_team.h", "fft_team_defer.h", "fft_team_list.h"):
+    for f in ("fft_device.h", "fft_codelets.h", "fft_kernels.h", "fft_team.h", "fft_team_defer.h", "fft_team_list.h", "fft_team_quad.h",
+              "fft_team_quad_decl.h", "fft_team_quad.hip"):
         with open(os.path.join(d, f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -538,11 +539,15 @@ def main():
         # the practical ceiling on this box, and an fp64 line (N = 2^19 is the largest fp64 team-kernel size)
         try:
             copy_torch = device_copy_gbs(torch, x, y if not args.inplace else torch.empty_like(x))
-            copy_own = lib.fft_gpu_copy_bench_hip(1 << 30, 5)  # hand-written 16-byte-per-lane copy, best of six launch shapes
+            # hand-written streams over 1 GiB, best of 12-13 launch shapes each (with / without the non-temporal hint, 1 / 4 / 8
+            # accesses in flight per thread, 8 / 16 workgroups per CU; copy: also an LDS-DMA tile copy in the engine's own shape)
+            copy_own = lib.fft_gpu_stream_bench_hip(1 << 30, 5, 0)
             copy = max(copy_torch, copy_own)
             result["roofline"]["copy_gbs"] = copy
             result["roofline"]["copy_gbs_torch"] = copy_torch
             result["roofline"]["copy_gbs_kernel"] = copy_own
+            result["roofline"]["read_gbs"] = lib.fft_gpu_stream_bench_hip(1 << 30, 5, 1)
+            result["roofline"]["write_gbs"] = lib.fft_gpu_stream_bench_hip(1 << 30, 5, 2)
             result["roofline"]["frac_of_copy"] = achieved / copy
         except Exception as e:
             result["roofline"]["copy_gbs"] = None

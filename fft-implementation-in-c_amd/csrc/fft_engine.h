@@ -267,7 +267,7 @@ class Pow2Plan {
         make_twiddle_table<T>(part, L * L, 2, L / 2);
         blob.push_back(part[1]);
         blob.push_back(part[0]);  // (pad to 16 bytes)
-        d.scratch_bytes = ((size_t)SZ << (log2TE + d.log2TS)) * 2 * (size_t)d.n_teams;  // two window slots per team
+        d.scratch_bytes = ((size_t)SZ << (log2TE + d.log2TS)) * 2 * (size_t)d.n_teams;  // two window slots per team (one used where the kernel is built with one)
         d.tables = (cpx<T>*)rt->dmalloc(blob.size() * SZ);
         d.scratch = (unsigned char*)rt->dmalloc(d.scratch_bytes);
         d.sticky = (unsigned*)rt->dmalloc((fftk::TEAM_STICKY_WORDS + fftk::TEAM_CTL_WORDS) * sizeof(unsigned));
@@ -278,9 +278,11 @@ class Pow2Plan {
         }
         rt->memset_async(d.sticky, 0, fftk::TEAM_STICKY_WORDS * sizeof(unsigned));
         rt->h2d(d.tables, blob.data(), blob.size() * SZ);
-        // (the batch crossover of the tile-by-tile team kernels, profiles/r2_batch_crossover.txt, until re-measured for this one)
+        // batch crossover against the multi-pass schedule (tools/batch_crossover.py 20,18,16; profiles/r3_batch_crossover.txt):
+        // n = 2^20 from 128 MiB per execute (117 vs 112 Gpoint/s at 16 transforms), 2^18 from 512 MiB (192 vs 169), 2^16 from 1 GiB
+        // (207 vs 185); and at least 4 transforms per team
         {
-            const long long mib = d.log2TS >= 5 ? 256 : d.log2TS == 3 ? 1024 : 2048;
+            const long long mib = d.log2TS >= 5 ? 128 : d.log2TS == 3 ? 512 : 1024;
             d.min_batch = mode == 1 ? (int)std::max<long long>(4ll * d.n_teams, (mib << 20) / ((long long)SZ << log2n)) : d.n_teams;
         }
         if (rt->policy.team_min_batch > 0) d.min_batch = rt->policy.team_min_batch;
@@ -293,13 +295,14 @@ class Pow2Plan {
         const long long grid = (long long)team.n_xcc << team.log2seats;
         if constexpr (SZ == 8) {
 #if defined(FFT_EMU)
-            if (log2n == 12) rt->launch_coresident(fftk::team_quad_kernel<T, 4, 2, 6, 2>, grid, team.nthreads, (size_t)team.smem_bytes, tp);
-            else if (team.log2TS == 1) rt->launch_coresident(fftk::team_quad_kernel<T, 4, 1, 5, 1>, grid, team.nthreads, (size_t)team.smem_bytes, tp);
-            else rt->launch_coresident(fftk::team_quad_kernel<T, 4, 1, 5, 2>, grid, team.nthreads, (size_t)team.smem_bytes, tp);
+            if (log2n == 12) rt->launch_coresident(fftk::team_quad_kernel<T, 4, 2, 6, 2, 2>, grid, team.nthreads, (size_t)team.smem_bytes, tp);
+            else if (team.log2TS == 1) rt->launch_coresident(fftk::team_quad_kernel<T, 4, 1, 5, 1, 1>, grid, team.nthreads, (size_t)team.smem_bytes, tp);
+            else rt->launch_coresident(fftk::team_quad_kernel<T, 4, 1, 5, 2, 1>, grid, team.nthreads, (size_t)team.smem_bytes, tp);
 #else
-            if (log2n == 20) rt->launch_coresident(fftk::team_quad_kernel<T, 16, 4, 10, 5>, grid, team.nthreads, (size_t)team.smem_bytes, tp);
-            else if (log2n == 18) rt->launch_coresident(fftk::team_quad_kernel<T, 16, 3, 9, 3>, grid, team.nthreads, (size_t)team.smem_bytes, tp);
-            else rt->launch_coresident(fftk::team_quad_kernel<T, 16, 2, 8, 1>, grid, team.nthreads, (size_t)team.smem_bytes, tp);
+            if (log2n == 20 && rt->team_quad_slots20() == 1) rt->launch_coresident(fftk::team_quad_kernel<T, 16, 4, 10, 5, 1>, grid, team.nthreads, (size_t)team.smem_bytes, tp);
+            else if (log2n == 20) rt->launch_coresident(fftk::team_quad_kernel<T, 16, 4, 10, 5, 2>, grid, team.nthreads, (size_t)team.smem_bytes, tp);
+            else if (log2n == 18) rt->launch_coresident(fftk::team_quad_kernel<T, 16, 3, 9, 3, 1>, grid, team.nthreads, (size_t)team.smem_bytes, tp);
+            else rt->launch_coresident(fftk::team_quad_kernel<T, 16, 2, 8, 1, 1>, grid, team.nthreads, (size_t)team.smem_bytes, tp);
 #endif
         }
         (void)grid;

@@ -165,6 +165,11 @@ struct HipRT {
         if (on <= 1) return on == 1;
         return (on & (log2n == 20 ? 2 : log2n == 18 ? 4 : 8)) != 0;
     }
+    // window slots of team_quad_kernel at n = 2^20 (the experiments build: FFT_HIP_QUAD_SLOTS20=1 runs the one-slot protocol)
+    int team_quad_slots20() {
+        static const int v = FFT_EXP_ENV("FFT_HIP_QUAD_SLOTS20") ? atoi(FFT_EXP_ENV("FFT_HIP_QUAD_SLOTS20")) : 2;
+        return v;
+    }
     bool team_alll2(int, int) {
         static const int on = FFT_EXP_ENV("FFT_HIP_TEAM_ALLL2") ? atoi(FFT_EXP_ENV("FFT_HIP_TEAM_ALLL2")) : 0;
         return on != 0;
@@ -832,8 +837,11 @@ int fft_gpu_host_is_registered_hip(const void* host_ptr) {
 }
 // Device copy benchmark on the current device: the best of a few launch shapes of copy16_kernel over `bytes` bytes
 // (read + written bytes per second, GB/s); what bench.py quotes as the box's practical ceiling.  -1 on failure.
-double fft_gpu_copy_bench_hip(size_t bytes, int iters) {
-    if (!g_initialized || bytes < (1u << 20) || iters <= 0) return -1.0;
+// mode 0 copy (read + written bytes per second), 1 read only, 2 write only: the best of several launch shapes (1 / 4 / 8
+// accesses in flight per thread, 8 or 16 workgroups per CU, with and without the non-temporal hint; copy: also the tile copy in
+// the engine's own shape, LDS-DMA in and nt stores out), GB/s; -1 on failure
+double fft_gpu_stream_bench_hip(size_t bytes, int iters, int mode) {
+    if (!g_initialized || bytes < (1u << 20) || iters <= 0 || mode < 0 || mode > 2) return -1.0;
     void *a = nullptr, *b = nullptr;
     if (hipMalloc(&a, bytes) != hipSuccess || hipMalloc(&b, bytes) != hipSuccess) {
         (void)hipGetLastError();
@@ -848,25 +856,40 @@ double fft_gpu_copy_bench_hip(size_t bytes, int iters) {
     const long long n16 = (long long)(bytes / 16);
     const DeviceInfo* di = device_info(g_device);
     const int cus = di ? di->cus : 256;
+    const fftk::vec16<float>* in = (const fftk::vec16<float>*)a;
+    fftk::vec16<float>* out = (fftk::vec16<float>*)b;
     double best = -1.0;
-    for (int shape = 0; shape < 6; shape++) {
-        const int per_cu = shape < 3 ? 8 : 16;  // resident 256-thread workgroups per CU
+    const int n_shapes = mode == 0 ? 13 : 12;
+    for (int shape = 0; shape < n_shapes; shape++) {
+        const int per_cu = (shape / 3) % 2 ? 16 : 8;  // resident 256-thread workgroups per CU
+        const bool nt = shape >= 6;
         const unsigned grid = (unsigned)(cus * per_cu);
         for (int rep = 0; rep < 2; rep++) {
             (void)hipEventRecord(e0, nullptr);
             for (int it = 0; it < iters; it++) {
-                switch (shape % 3) {
-                    case 0: hipLaunchKernelGGL(fftk::copy16_kernel<1>, dim3(grid), dim3(256), 0, nullptr, (const fftk::vec16<float>*)a, (fftk::vec16<float>*)b, n16); break;
-                    case 1: hipLaunchKernelGGL(fftk::copy16_kernel<4>, dim3(grid), dim3(256), 0, nullptr, (const fftk::vec16<float>*)a, (fftk::vec16<float>*)b, n16); break;
-                    default: hipLaunchKernelGGL(fftk::copy16_kernel<8>, dim3(grid), dim3(256), 0, nullptr, (const fftk::vec16<float>*)a, (fftk::vec16<float>*)b, n16); break;
+                if (shape == 12) {
+                    const void* key = reinterpret_cast<const void*>(fftk::copy_dma_kernel);
+                    (void)hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+                    hipLaunchKernelGGL(fftk::copy_dma_kernel, dim3((unsigned)cus), dim3(512), 131072, nullptr, in, out, (long long)(bytes / 65536));
+                    continue;
                 }
+#define FFT_STREAM_LAUNCH(U, M, N) hipLaunchKernelGGL((fftk::stream16_kernel<U, M, N>), dim3(grid), dim3(256), 0, nullptr, in, out, n16)
+#define FFT_STREAM_MODE(M)                                                                                        \
+    switch (shape % 3) {                                                                                          \
+        case 0: if (nt) FFT_STREAM_LAUNCH(1, M, 1); else FFT_STREAM_LAUNCH(1, M, 0); break;                       \
+        case 1: if (nt) FFT_STREAM_LAUNCH(4, M, 1); else FFT_STREAM_LAUNCH(4, M, 0); break;                       \
+        default: if (nt) FFT_STREAM_LAUNCH(8, M, 1); else FFT_STREAM_LAUNCH(8, M, 0); break;                      \
+    }
+                if (mode == 0) { FFT_STREAM_MODE(0) } else if (mode == 1) { FFT_STREAM_MODE(1) } else { FFT_STREAM_MODE(2) }
+#undef FFT_STREAM_MODE
+#undef FFT_STREAM_LAUNCH
             }
             (void)hipEventRecord(e1, nullptr);
             if (hipEventSynchronize(e1) != hipSuccess) break;
             float ms = 0.f;
             (void)hipEventElapsedTime(&ms, e0, e1);
             if (rep == 1 && ms > 0.f) {
-                const double gbs = 2.0 * (double)bytes * iters / (ms * 1e-3) / 1e9;
+                const double gbs = (mode == 0 ? 2.0 : 1.0) * (double)bytes * iters / (ms * 1e-3) / 1e9;
                 if (gbs > best) best = gbs;
             }
         }
@@ -878,6 +901,7 @@ double fft_gpu_copy_bench_hip(size_t bytes, int iters) {
     (void)hipGetLastError();
     return best;
 }
+double fft_gpu_copy_bench_hip(size_t bytes, int iters) { return fft_gpu_stream_bench_hip(bytes, iters, 0); }
 void fft_gpu_debug_counters_hip(long long* device_allocations, long long* streams_created) {
     if (device_allocations) *device_allocations = __atomic_load_n(&g_count_allocs, __ATOMIC_RELAXED);
     if (streams_created) *streams_created = __atomic_load_n(&g_count_streams, __ATOMIC_RELAXED);

@@ -128,20 +128,67 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS(256) psd_onesided_kernel(const cpx<T>* X, T* p
     }
 }
 
-// Plain device copy, 16 bytes per lane, `unroll` independent accesses in flight per thread, grid-stride: the practical HBM
-// ceiling of the box the benchmark runs on (MI355X_MICROARCH.md quotes 6.29 TB/s for a float4 copy).
-template <int UNROLL>
-FFT_KERNEL void FFT_LAUNCH_BOUNDS(256) copy16_kernel(const vec16<float>* in, vec16<float>* out, long long n16) {
+// Device streams, 16 bytes per lane, `unroll` independent accesses in flight per thread, grid-stride: the practical ceiling
+// of the box the benchmark runs on (MI355X_MICROARCH.md quotes 6.29 TB/s for a float4 copy).  MODE 0 copy, 1 read only (the
+// values are folded into one word that is stored only if it is a NaN pattern the inputs never hold), 2 write only.  NT: the
+// non-temporal hint on both sides -- what the FFT kernels' own streams carry.
+template <int UNROLL, int MODE, int NT>
+FFT_KERNEL void FFT_LAUNCH_BOUNDS(256) stream16_kernel(const vec16<float>* in, vec16<float>* out, long long n16) {
     const long long stride = FFT_NBLOCKS * FFT_NTHREADS;
     long long i = FFT_BID * FFT_NTHREADS + FFT_TID;
+    vec16<float> acc;
+    acc.c[0] = mk<float>(0.f, 0.f);
+    acc.c[1] = mk<float>(1.f, 2.f);
     for (; i + (UNROLL - 1) * stride < n16; i += UNROLL * stride) {
         vec16<float> v[UNROLL];
         FFT_UNROLL
-        for (int u = 0; u < UNROLL; u++) v[u] = in[i + u * stride];
-        FFT_UNROLL
-        for (int u = 0; u < UNROLL; u++) out[i + u * stride] = v[u];
+        for (int u = 0; u < UNROLL; u++) v[u] = MODE == 2 ? acc : fft_ld16<NT>(in + i + u * stride);
+        if (MODE == 1) {
+            FFT_UNROLL
+            for (int u = 0; u < UNROLL; u++) {
+                acc.c[0].re += v[u].c[0].re;
+                acc.c[0].im += v[u].c[1].im;
+            }
+        } else {
+            FFT_UNROLL
+            for (int u = 0; u < UNROLL; u++) fft_st16<NT>(out + i + u * stride, v[u]);
+        }
     }
-    for (; i < n16; i += stride) out[i] = in[i];
+    for (; i < n16; i += stride) {
+        if (MODE == 1) acc.c[0].re += fft_ld16<NT>(in + i).c[0].re;
+        else fft_st16<NT>(out + i, MODE == 2 ? acc : fft_ld16<NT>(in + i));
+    }
+    if (MODE == 1 && acc.c[0].re != acc.c[0].re && acc.c[0].im == 12345.f) out[0] = acc;
 }
+
+#if !defined(FFT_EMU)
+// The copy in the shape of the engine's own kernels: one 512-thread workgroup per CU walks 64 KiB tiles, tile t + 1 lands in
+// LDS by LDS-DMA (nt) while tile t leaves it through registers (ds_read_b128 + nt stores): two tiles of reads in flight per CU.
+FFT_KERNEL void FFT_LAUNCH_BOUNDS(512) copy_dma_kernel(const vec16<float>* in, vec16<float>* out, long long n_tiles) {
+    FFT_DYN_SMEM(smem);  // 2 x 64 KiB
+    const int tid = FFT_TID;
+    const unsigned lds0 = FFT_LDS_ADDR(smem);
+    long long t = FFT_BID;
+    auto dma = [&](long long tile, int im) __attribute__((always_inline)) {
+        const vec16<float>* src = in + tile * 4096 + tid;
+        FFT_UNROLL
+        for (int i = 0; i < 8; i++) fft_dma16<2>(src + i * 512, lds0 + (unsigned)im * 65536u + (unsigned)(i * 512 + tid) * 16u);
+    };
+    if (t < n_tiles) dma(t, 0);
+    int im = 0;
+    for (; t < n_tiles; t += FFT_NBLOCKS, im ^= 1) {
+        FFT_WAIT_VM_LE(8);  // everything but my 8 stores of the previous tile: this tile has landed
+        FFT_SYNC_LDS();
+        if (t + FFT_NBLOCKS < n_tiles) dma(t + FFT_NBLOCKS, im ^ 1);
+        const vec16<float>* img = reinterpret_cast<const vec16<float>*>(smem + im * 65536);
+        vec16<float> v[8];
+        FFT_UNROLL
+        for (int i = 0; i < 8; i++) v[i] = img[i * 512 + tid];
+        FFT_UNROLL
+        for (int i = 0; i < 8; i++) FFT_STORE16_NT(out + t * 4096 + i * 512 + tid, v[i]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+#endif
 
 }  // namespace fftk

@@ -192,8 +192,16 @@ FFT_DEVICE void quad_twiddle_kb(cpx<T> (&x)[E], const cpx<T> (&v)[E], const cpx<
     }
 }
 
-template <typename T, int E, int LOG2R2, int LOG2L, int LOG2TS>
+// SLOTS: window slots per team.  2 (4 MiB of window per XCD): round r + 2 is written into the slot round r came from, every team wait
+// has a whole round of slack -- but 4 MiB of window do not stay in the 4 MiB L2: every window byte is written back once and a fifth
+// of the window reads miss (memory-side traffic 1.58 x the algorithmic bytes, profiles/r3_pmc_oneslot.txt).  1 (2 MiB per XCD): the
+// slot is rewritten in L2 (traffic 1.08 x), at the price of strict alternation -- write, everybody reads, write -- with eight
+// arrivals per transform and two team waits per round that sit on the critical path.  Measured (profiles/r3_ab_quad.txt): teams of 2
+// (n = 2^16) +6.5 % with one slot, teams of 8 (2^18) +-1 %, teams of 32 (2^20) -20 %.
+template <typename T, int E, int LOG2R2, int LOG2L, int LOG2TS, int SLOTS>
 FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2R2, LOG2L, LOG2TS) team_quad_kernel(TeamParams<T> p) {
+    constexpr bool QUAD_ONE_SLOT = SLOTS == 1;
+    static_assert(SLOTS == 1 || SLOTS == 2, "one or two window slots");
     static_assert(vec16<T>::V == 2, "fp32: a 16-byte access holds the values of two adjacent rows");
     using S = QuadShape<E, LOG2R2, LOG2L, LOG2TS>;
     constexpr int L = S::L, TS = S::TS, M = S::M, NC = S::NC, LOG2NC = S::LOG2NC, NTHR = S::NTHR, R2 = S::R2, G2 = S::G2, ILN = S::ILN;
@@ -235,7 +243,7 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2R2, LOG2L, LOG2TS) team_quad_kernel(TeamPara
     if (NTR == 0) return;
     if (FFT_TEST_DROP()) return;  // emulation only: a member that never arrives
 
-    unsigned char* const sbase = p.scratch + (size_t)team * 2 * SLOT;
+    unsigned char* const sbase = p.scratch + (size_t)team * SLOTS * SLOT;
     unsigned* const flags = p.ctl + TEAM_CTL_FLAGS + 32 * team;
 
     int n_ev = 0;
@@ -335,7 +343,7 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2R2, LOG2L, LOG2TS) team_quad_kernel(TeamPara
     for (int it = 0; it < NTR; it++) {
         const cpx<T>* inb = in_of(it);
         cpx<T>* outb = out_of(it);
-        const int G = 5 * it;  // arrivals made before this transform
+        const int G = (QUAD_ONE_SLOT ? 8 : 5) * it;  // arrivals made before this transform
 
         // ================= column step: four chunks, length-M transforms, results x W_L^(a kb) kept
         cpx<T> blk[4][E];
@@ -400,7 +408,7 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2R2, LOG2L, LOG2TS) team_quad_kernel(TeamPara
             FFT_OPAQUE(t);
             const int g = t & (R2 - 1);
             const int q = (r - ap) & 3;
-            unsigned char* const wslot = sbase + (size_t)(r & 1) * SLOT;
+            unsigned char* const wslot = sbase + (size_t)(QUAD_ONE_SLOT ? 0 : (r & 1)) * SLOT;
             const int bprime = (NC / 4) * s + sender_cc(t);  // (j2 - ap) / 4: my column's place in its class
             FFT_UNROLL
             for (int i = 0; i < E / 2; i++) {
@@ -456,17 +464,20 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2R2, LOG2L, LOG2TS) team_quad_kernel(TeamPara
                     FFT_UNROLL
                     for (int k = 0; k < R2; k++) blk[r][i * R2 + k] = cmul(blk[r][i * R2 + k], w[k]);
                 }
-                if (r == 0) send(0);  // drains under block 1's twiddles
+                if (r == 0) {
+                    if (QUAD_ONE_SLOT) wait_all(G);  // the slot was last read in the previous transform's round 3: long true
+                    send(0);  // drains under block 1's twiddles
+                }
                 if (r == 1) {
                     // ================= exchange + row step begins: the team learns that my round-0 values are in L2 while I
                     // still twiddle blocks 2 and 3 (the first team wait absorbs the column step's skew: work behind the
                     // arrival is free)
-                    wait_all(G);  // everybody's image of the previous transform's round 3 has landed: long true
+                    if (!QUAD_ONE_SLOT) wait_all(G);  // everybody's image of the previous transform's round 3 has landed: long true
                     FFT_WAIT_VM0();
                     FFT_SYNC_LDS();
                     arrive();  // arrival G + 1
                     ev();
-                    send(1);  // slot 1 was last read in that round 3
+                    if (!QUAD_ONE_SLOT) send(1);  // slot 1 was last read in that round 3
                 }
             }
         }
@@ -475,6 +486,47 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2R2, LOG2L, LOG2TS) team_quad_kernel(TeamPara
         wait_all(G + 1);
         ev();
         dma_window(0, 0);
+        if constexpr (QUAD_ONE_SLOT) {
+        // One slot: round r + 1 may be written once EVERYBODY's image of round r has landed, and read once everybody's values
+        // are in L2 -- arrivals S_r = G + 2 r + 1 ("my values of round r are in L2") and L_r = G + 2 r + 2 ("my image of round r
+        // has landed") alternate.  The values of round r + 1 go out right behind L_r and drain under round r's first stage; the
+        // image of round r + 1 is requested at the stage barrier and flies under the second stage.
+        FFT_UNROLL
+        for (int r = 0; r < 4; r++) {
+            FFT_WAIT_VM0();  // the round's image has landed ...
+            FFT_SYNC_LDS();  // ... everybody's of this workgroup
+            arrive();  // L_r
+            ev();
+            if (r == 3 && it + 1 < NTR) dma_chunk(in_of(it + 1), 0, 0);  // image 0 was last read in round 2
+            if (r < 3) {
+                wait_all(G + 2 * r + 2);  // the team's
+                send(r + 1);
+            }
+            cpx<T>* img = reinterpret_cast<cpx<T>*>(img_b[r & 1]);
+            int t = tid0;
+            FFT_OPAQUE(t);
+            quad_stage1<T, E, R2, LOG2NC, LOG2L, false>(img, wl, t & (NC - 1), t >> LOG2NC, false);
+            if (r < 3) FFT_WAIT_VM0();  // my round-(r + 1) values are in L2
+            FFT_SYNC_LDS();
+            if (r < 3) arrive();  // S_(r+1)
+            FFT_OPAQUE(t);
+            const int nr = t >> LOG2NC;
+            cpx<T> v[E];
+            quad_stage2_read<T, E, LOG2NC>(v, img, t & (NC - 1), nr);
+            if (r < 3) {
+                wait_all(G + 2 * r + 3);  // everybody's values of round r + 1 are in L2
+                ev();
+                dma_window(0, (r + 1) & 1);
+            }
+            quad_stage2_dft<T, E, R2>(v);
+            const int apr = (r - sigma) & 3;  // the class this round delivered to my row
+            if (apr != 0) quad_twiddle_kb<T, E, R2, LOG2L>(zt[r], v, wl, apr, nr, 0);  // W_L^(apr kb): < 3 M
+            else {
+                FFT_UNROLL
+                for (int k = 0; k < E; k++) zt[r][k] = v[k];
+            }
+        }
+        } else {
         FFT_UNROLL
         for (int r = 0; r < 4; r++) {
             FFT_WAIT_VM0();  // the round's image has landed and my round-(r + 1) values are in L2 ...
@@ -507,6 +559,7 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2R2, LOG2L, LOG2TS) team_quad_kernel(TeamPara
                 FFT_UNROLL
                 for (int k = 0; k < E; k++) zt[r][k] = v[k];
             }
+        }
         }
         // ---- final radix-4 over the rounds, modulation, transposed store: X[k1 + L k2], k1 = NC s + rho, k2 = kb + M ka; the
         // lanes of rows rho, rho ^ 1 pair up so that every store is 16 bytes and every wave instruction writes whole NC-row

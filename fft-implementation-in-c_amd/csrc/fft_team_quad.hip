@@ -3,7 +3,8 @@
 #include "fft_team_quad.h"
 
 namespace fftk {
-template __global__ void team_quad_kernel<float, 16, 4, 10, 5>(TeamParams<float>);  // n = 2^20: 1024 x 1024, teams of 32 (a whole XCD)
-template __global__ void team_quad_kernel<float, 16, 3, 9, 3>(TeamParams<float>);   // n = 2^18: 512 x 512, teams of 8
-template __global__ void team_quad_kernel<float, 16, 2, 8, 1>(TeamParams<float>);    // n = 2^16: 256 x 256, teams of 2
+template __global__ void team_quad_kernel<float, 16, 4, 10, 5, 2>(TeamParams<float>);  // n = 2^20: 1024 x 1024, teams of 32 (a whole XCD), two window slots
+template __global__ void team_quad_kernel<float, 16, 4, 10, 5, 1>(TeamParams<float>);  // ... with one (experiments: FFT_HIP_QUAD_SLOTS20=1; traffic 1.08 x, but -20 %)
+template __global__ void team_quad_kernel<float, 16, 3, 9, 3, 1>(TeamParams<float>);   // n = 2^18: 512 x 512, teams of 8, one window slot
+template __global__ void team_quad_kernel<float, 16, 2, 8, 1, 1>(TeamParams<float>);    // n = 2^16: 256 x 256, teams of 2, one window slot
 }

@@ -64,7 +64,7 @@ SIGNATURES = {
     "fft_gpu_plan_fused_hip": (_vp, [_i, _i, _i, _vp, _i, _i]), "fft_gpu_fused_out_len_hip": (_i, [_vp]),
     "fft_gpu_execute_fused_hip": (_i, [_vp, _vp, _vp, _vp, C.c_double]),
     "fft_gpu_host_register_hip": (_i, [_vp, _sz]), "fft_gpu_host_unregister_hip": (_i, [_vp]),
-    "fft_gpu_host_is_registered_hip": (_i, [_vp]), "fft_gpu_copy_bench_hip": (C.c_double, [_sz, _i]),
+    "fft_gpu_host_is_registered_hip": (_i, [_vp]), "fft_gpu_copy_bench_hip": (C.c_double, [_sz, _i]), "fft_gpu_stream_bench_hip": (C.c_double, [_sz, _i, _i]),
     "fft_gpu_debug_counters_hip": (None, [C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "fft_gpu_plan_measure_hip": (_i, [_vp, _i]),
     "fft_gpu_plan_team_status_hip": (_i, [_vp]), "fft_gpu_plan_team_trace_hip": (_i, [_vp, _vp, _i]),

@@ -132,6 +132,9 @@ int fft_gpu_host_is_registered_hip(const void* host_ptr); /* 1 page-locked and k
 /* the box's practical memory ceiling: best read + write rate (GB/s) of a plain 16-byte-per-lane device copy over `bytes`
  * bytes, a few launch shapes, `iters` launches each; -1 on failure */
 double fft_gpu_copy_bench_hip(size_t bytes, int iters);
+/* the same yardstick per direction: mode 0 copy (read + written bytes / s), 1 read-only stream, 2 write-only stream; the best of
+ * several launch shapes with and without the non-temporal hint (copy: also an LDS-DMA tile copy in the engine's own shape), GB/s */
+double fft_gpu_stream_bench_hip(size_t bytes, int iters, int mode);
 /* resource counters of this process (tests): device allocations and streams the backend has created so far */
 void fft_gpu_debug_counters_hip(long long* device_allocations, long long* streams_created);
 /* FFT_MEASURE at the device level: time the plan's candidate schedules (team kernel vs multi-pass) on scratch buffers of

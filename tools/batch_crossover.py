@@ -13,7 +13,10 @@ import fftlib  # noqa: E402
 
 def main():
     fftlib.init()
-    for log2n, dtype in ((20, np.complex64), (19, np.complex64), (18, np.complex64), (17, np.complex64), (16, np.complex64), (19, np.complex128), (17, np.complex128), (15, np.complex128)):
+    sizes = ((20, np.complex64), (19, np.complex64), (18, np.complex64), (17, np.complex64), (16, np.complex64), (19, np.complex128), (17, np.complex128), (15, np.complex128))
+    if len(sys.argv) > 1:  # e.g. "20,18,16": fp32 sizes only (round 3: team_quad_kernel)
+        sizes = tuple((int(v), np.complex64) for v in sys.argv[1].split(","))
+    for log2n, dtype in sizes:
         n = 1 << log2n
         esz = np.dtype(dtype).itemsize
         for batch in (8, 16, 32, 64, 128, 256, 512):
