@@ -44,8 +44,15 @@
 #include "fft_team_defer.h"
 #if defined(FFT_EMU)
 #include "fft_team_quad.h"
+#include "fft_wide_row.h"
 #else
 #include "fft_team_quad_decl.h"
+#define FFT_WIDE_DECL_ONLY
+#include "fft_wide_row.h"
+namespace fftk {
+extern template __global__ void wide_row_kernel<float, 13>(WideParams<float>);
+extern template __global__ void wide_row_kernel<float, 14>(WideParams<float>);
+}
 #endif
 
 namespace ffteng {
@@ -212,6 +219,8 @@ class Pow2Plan {
         scratch2 = nullptr;
         delete mirror;
         mirror = nullptr;
+        if (wide.tables) rt->dfree(wide.tables);
+        wide = WideDesc();
         if (team.tables) rt->dfree(team.tables);
         if (team.scratch) rt->dfree(team.scratch);
         if (team.sticky) rt->dfree(team.sticky);
@@ -223,6 +232,52 @@ class Pow2Plan {
     // ---- team_quad_kernel (fft_team_quad.h): n = L x L with L = 4 E^2, teams of TS = n / (4 tiles) seats.  Built for fp32
     // n = 2^20 on the device (E = 16, a whole XCD per transform) and for n = 2^12 in the emulation (E = 4, 64-thread
     // workgroups, teams of 4).  Tables [W_n^x, x < L | W_L^y, y < L]; window: 2 slots of TS images per team.
+    // ---- wide_row_kernel (fft_wide_row.h): single-pass n = 8192 fp32 (the emulation: n = 512, 32 threads)
+    struct WideDesc {
+        bool ok = false;
+        int nthreads = 0, smem_bytes = 0, tables_elems = 0, o_sb = 0, sa_bits = 0;
+        cpx<T>* tables = nullptr;
+    } wide;
+    void build_wide() {
+        if (SZ != 8 || !rt->wide_rows(SZ, log2n)) return;
+        const long long L = 1ll << log2n;
+        WideDesc d;
+        d.nthreads = (int)(L / 16);
+        d.sa_bits = fftk::team_stage_table_bits(SZ, log2n);
+        d.o_sb = 1 << d.sa_bits;
+        int ne = d.o_sb + (1 << (log2n - d.sa_bits));
+        ne = (ne * SZ + 15) / 16 * 16 / SZ;
+        d.tables_elems = ne;
+        d.smem_bytes = (int)((2 * L * SZ > 140 * 1024 ? 1 : 2) * L * SZ) + ne * SZ;  // n = 16384: one image, run in place
+        if (d.smem_bytes > rt->max_lds_bytes()) return;
+        std::vector<cpx<T>> blob((size_t)ne), part;
+        for (auto& z : blob) { z.re = (T)1; z.im = (T)0; }
+        make_twiddle_table<T>(part, L, 1ll << d.sa_bits, 1);
+        std::copy(part.begin(), part.end(), blob.begin());
+        make_twiddle_table<T>(part, L, 1ll << (log2n - d.sa_bits), 1ll << d.sa_bits);
+        std::copy(part.begin(), part.end(), blob.begin() + d.o_sb);
+        d.tables = (cpx<T>*)rt->dmalloc(blob.size() * SZ);
+        if (!d.tables) return;
+        rt->h2d(d.tables, blob.data(), blob.size() * SZ);
+        d.ok = true;
+        wide = d;
+    }
+    void launch_wide(const cpx<T>* in, cpx<T>* out, int nb, bool inverse, T scale) {
+        if constexpr (SZ == 8) {
+            fftk::WideParams<T> wp;
+            memset(&wp, 0, sizeof(wp));
+            wp.in = in; wp.out = out; wp.tables = wide.tables; wp.tables_bytes = wide.tables_elems * SZ;
+            wp.o_sb = wide.o_sb; wp.sa_bits = wide.sa_bits; wp.nb = nb; wp.inverse = inverse ? 1 : 0; wp.nt = 3; wp.scale = scale;
+            const long long grid = std::min<long long>(nb, rt->num_cus());
+#if defined(FFT_EMU)
+            rt->launch(fftk::wide_row_kernel<T, 9>, grid, wide.nthreads, (size_t)wide.smem_bytes, wp);
+#else
+            if (log2n == 14) rt->launch(fftk::wide_row_kernel<T, 14>, grid, wide.nthreads, (size_t)wide.smem_bytes, wp);
+            else rt->launch(fftk::wide_row_kernel<T, 13>, grid, wide.nthreads, (size_t)wide.smem_bytes, wp);
+#endif
+        }
+    }
+
     // ---- team_quad_kernel (fft_team_quad.h): n = L x L, L = 4 M, M = E R2 (E values per thread and chunk, a radix-E and a radix-R2
     // stage), teams of TS = L R2 / threads seats.  Device (512 threads, E = 16): n = 2^20 (R2 16, teams of 32), 2^18 (R2 8, teams of
     // 8), 2^16 (R2 4, teams of 2); emulation (E = 4): n = 2^12 (R2 4) and 2^10 (R2 2).  Tables [W_n^x, x < L/2 | W_L^y, y < L |
@@ -857,6 +912,7 @@ class Pow2Plan {
             }
             if (prefer_chain && algo_ == ALGO_AUTO && !tables_only && (mirror || ends_chainable(passes.front(), passes.back()))) scratch2 = (cpx<T>*)rt->dmalloc(scratch_bytes);
         }
+        if (algo_ == ALGO_AUTO && !wants_hooks && !tables_only) build_wide();
         if (passes.size() > 1 && algo_ == ALGO_AUTO && !tables_only) {
             build_team_quad(batch);
             if (!team.ok) build_team(batch);
@@ -1408,6 +1464,11 @@ class Pow2Plan {
             for (int s = 1; s <= log2n; s++)
                 rt->launch(fftk::radix2_dit_stage_kernel<T>, grid_for(total / 2, 256), 256, (size_t)0, out,
                            (const cpx<T>*)tw_half, log2n, s, total / 2, inverse ? 1 : 0, s == log2n ? scale : (T)1);
+            return;
+        }
+        if (wide.ok) {  // n = 8192 fp32: one round trip (fft_wide_row.h) instead of the two-pass schedule
+            launch_wide(in, out, nb, inverse, scale);
+            rt->mark(0);
             return;
         }
         if (passes.size() == 1) {

@@ -170,6 +170,11 @@ struct HipRT {
         static const int v = FFT_EXP_ENV("FFT_HIP_QUAD_SLOTS20") ? atoi(FFT_EXP_ENV("FFT_HIP_QUAD_SLOTS20")) : 2;
         return v;
     }
+    // wide_row_kernel (fft_wide_row.h): single-pass n = 8192 and 16384 fp32.  FFT_HIP_WIDE=0 (the experiments build): the two-pass schedule
+    bool wide_rows(int elem_bytes, int log2n) {
+        static const int on = FFT_EXP_ENV("FFT_HIP_WIDE") ? atoi(FFT_EXP_ENV("FFT_HIP_WIDE")) : 1;
+        return on && gfx950 && elem_bytes == 8 && (log2n == 13 || log2n == 14);
+    }
     bool team_alll2(int, int) {
         static const int on = FFT_EXP_ENV("FFT_HIP_TEAM_ALLL2") ? atoi(FFT_EXP_ENV("FFT_HIP_TEAM_ALLL2")) : 0;
         return on != 0;
@@ -1070,7 +1075,7 @@ int fft_gpu_plan_info_hip(fft_gpu_plan_t p, fft_gpu_plan_info_t* info) {
         } else if (core->algo == ffteng::ALGO_RADIX2_GLOBAL) {
             info->n_passes = core->log2n + 1;
         } else {
-            info->n_passes = (int)core->passes.size();
+            info->n_passes = core->wide.ok ? 1 : (int)core->passes.size();
             for (size_t i = 0; i < core->passes.size() && i < 4; i++) info->factors[i] = 1 << core->passes[i].log2L;
         }
     };

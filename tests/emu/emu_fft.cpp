@@ -124,6 +124,7 @@ static int run(const void* in, void* out, int n, int batch, int dir, int algo, i
             info[7] = plan.chunk;
             if (plan.team.ok) info[0] += 100 * plan.team.NT;  // 100*NT + passes: the team kernel is planned
             info[6] = plan.team.ok ? (plan.team.asplit ? 1 : 0) + (plan.team.defer ? 2 : 0) + (plan.team.pair ? 4 : 0) + (plan.team.quad ? 8 : 0) : 0;
+            if (plan.wide.ok) info[6] |= 16;  // wide_row_kernel (fft_wide_row.h) runs the plain executes
         }
         plan.execute((const C*)in, (C*)out, batch, dir > 0);
         if (plan.team.ctl && getenv("FFT_EMU_RECOVER")) {

@@ -185,6 +185,20 @@ def test_team_kernel(n, batch, dtype, log2seats, n_xcc, threads, lds, tiles, pla
             assert rel(y, oracle(x, d)) < TEAM_TOL[dtype], (n, d, inplace)
 
 
+def test_wide_row_kernel(monkeypatch):
+    """wide_row_kernel (fft_wide_row.h; the device runs it at n = 8192 fp32: 512 threads x 16 values) in its emulated shape: n = 512,
+    32 threads, radix-16 x 16 x 2, one row per workgroup step with the next row's LDS-DMA issued under the stages; ragged batches over
+    the 3 emulated CUs, both directions, in place and out of place."""
+    monkeypatch.setenv("FFT_EMU_WIDE", "1")
+    for batch in (1, 3, 7):
+        x = O.gen_lcg(512, 37, batch).astype(np.complex64)
+        for d in (-1, 1):
+            for inplace in (False, True):
+                y, info = E.emu_fft(x, d, inplace=inplace)
+                assert info[6] & 16, "wide_row_kernel was not planned"
+                assert rel(y, oracle(x, d)) < TEAM_TOL[np.complex64], (batch, d, inplace)
+
+
 QUAD_CASES = [  # n, batch, log2seats, "XCDs", threads, LDS bytes
     (4096, 2, 2, 2, 64, 8192),    # E = 4, M = 4 x 4, teams of 4 seats of 64 threads (NC = 16): every seat in a row block of its own
     (4096, 9, 2, 1, 64, 8192),    # ragged batch on one "XCD"

@@ -17,6 +17,7 @@ def main():
     dtype = np.complex128 if (len(sys.argv) > 3 and sys.argv[3] == "f64") else np.complex64
     tag = sys.argv[4] if len(sys.argv) > 4 else ""
     n = 1 << log2n
+    assert batch % 8 == 0, "the inputs are 8 distinct transforms, tiled"
     fftlib.init()
     x8 = O.gen_lcg(n, 3, 8).astype(dtype)
     x = np.tile(x8, (batch // 8, 1))
