@@ -52,6 +52,7 @@
 namespace fftk {
 extern template __global__ void wide_row_kernel<float, 13>(WideParams<float>);
 extern template __global__ void wide_row_kernel<float, 14>(WideParams<float>);
+extern template __global__ void wide_row_kernel<double, 13, 16>(WideParams<double>);
 }
 #endif
 
@@ -239,7 +240,7 @@ class Pow2Plan {
         cpx<T>* tables = nullptr;
     } wide;
     void build_wide() {
-        if (SZ != 8 || !rt->wide_rows(SZ, log2n)) return;
+        if (!rt->wide_rows(SZ, log2n)) return;
         const long long L = 1ll << log2n;
         WideDesc d;
         d.nthreads = (int)(L / 16);
@@ -263,6 +264,15 @@ class Pow2Plan {
         wide = d;
     }
     void launch_wide(const cpx<T>* in, cpx<T>* out, int nb, bool inverse, T scale) {
+        if constexpr (SZ == 16) {
+#if !defined(FFT_EMU)
+            fftk::WideParams<T> wp;
+            memset(&wp, 0, sizeof(wp));
+            wp.in = in; wp.out = out; wp.tables = wide.tables; wp.tables_bytes = wide.tables_elems * SZ;
+            wp.o_sb = wide.o_sb; wp.sa_bits = wide.sa_bits; wp.nb = nb; wp.inverse = inverse ? 1 : 0; wp.nt = 3; wp.scale = scale;
+            rt->launch(fftk::wide_row_kernel<T, 13, 16>, std::min<long long>(nb, rt->num_cus()), wide.nthreads, (size_t)wide.smem_bytes, wp);
+#endif
+        }
         if constexpr (SZ == 8) {
             fftk::WideParams<T> wp;
             memset(&wp, 0, sizeof(wp));

@@ -173,7 +173,7 @@ struct HipRT {
     // wide_row_kernel (fft_wide_row.h): single-pass n = 8192 and 16384 fp32.  FFT_HIP_WIDE=0 (the experiments build): the two-pass schedule
     bool wide_rows(int elem_bytes, int log2n) {
         static const int on = FFT_EXP_ENV("FFT_HIP_WIDE") ? atoi(FFT_EXP_ENV("FFT_HIP_WIDE")) : 1;
-        return on && gfx950 && elem_bytes == 8 && (log2n == 13 || log2n == 14);
+        return on && gfx950 && ((elem_bytes == 8 && (log2n == 13 || log2n == 14)) || (elem_bytes == 16 && log2n == 13));
     }
     bool team_alll2(int, int) {
         static const int on = FFT_EXP_ENV("FFT_HIP_TEAM_ALLL2") ? atoi(FFT_EXP_ENV("FFT_HIP_TEAM_ALLL2")) : 0;

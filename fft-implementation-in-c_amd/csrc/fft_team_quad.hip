@@ -10,4 +10,5 @@ template __global__ void team_quad_kernel<float, 16, 3, 9, 3, 1>(TeamParams<floa
 template __global__ void team_quad_kernel<float, 16, 2, 8, 1, 1>(TeamParams<float>);    // n = 2^16: 256 x 256, teams of 2, one window slot
 template __global__ void wide_row_kernel<float, 13>(WideParams<float>);  // single-pass n = 8192 (fft_wide_row.h)
 template __global__ void wide_row_kernel<float, 14>(WideParams<float>);  // single-pass n = 16384
+template __global__ void wide_row_kernel<double, 13, 16>(WideParams<double>);  // fp64 n = 8192: 512 threads, one 128 KiB image in place
 }

@@ -1,4 +1,4 @@
-// fft_wide_row.h -- wide_row_kernel: single-pass transforms of n = 8192 and 16384 fp32 (one HBM round trip), the sizes just above
+// fft_wide_row.h -- wide_row_kernel: single-pass transforms of n = 8192 and 16384 fp32 and n = 8192 fp64 (one HBM round trip), the sizes just above
 // what the tile kernels' 512 threads x 8 values reach (fft_kernels.h: n <= 4096).
 //
 // One 512-thread workgroup per CU walks the batch; a transform is ONE 64 KiB row: it lands in LDS by LDS-DMA (nt; the next row
@@ -27,20 +27,21 @@ struct WideParams {
 };
 
 #if defined(FFT_EMU)
-#define FFT_WIDE_BOUNDS(LOG2L)
+#define FFT_WIDE_BOUNDS(LOG2L, E)
 #else
-#define FFT_WIDE_BOUNDS(LOG2L) __launch_bounds__((1 << (LOG2L)) / 16, ((1 << (LOG2L)) / 16) / 256)
+#define FFT_WIDE_BOUNDS(LOG2L, E) __launch_bounds__((1 << (LOG2L)) / (E), ((1 << (LOG2L)) / (E)) / 256)
 #endif
 
-template <typename T, int LOG2L>
-FFT_KERNEL void FFT_WIDE_BOUNDS(LOG2L) wide_row_kernel(WideParams<T> p);
+// E = values per thread = the radix of the stages (plus one stage of the remaining power of two)
+template <typename T, int LOG2L, int E = 16>
+FFT_KERNEL void FFT_WIDE_BOUNDS(LOG2L, E) wide_row_kernel(WideParams<T> p);
 
 #if !defined(FFT_WIDE_DECL_ONLY)
-template <typename T, int LOG2L>
-FFT_KERNEL void FFT_WIDE_BOUNDS(LOG2L) wide_row_kernel(WideParams<T> p) {
-    static_assert(vec16<T>::V == 2, "fp32");
-    constexpr int E = 16, L = 1 << LOG2L, NTHR = L / E, NCH = E / 2, log2TPC = LOG2L - 4;
-    constexpr unsigned IMG = (unsigned)L * 8u;
+template <typename T, int LOG2L, int E>
+FFT_KERNEL void FFT_WIDE_BOUNDS(LOG2L, E) wide_row_kernel(WideParams<T> p) {
+    constexpr int V16 = vec16<T>::V;  // values per 16-byte access: 2 (fp32), 1 (fp64)
+    constexpr int L = 1 << LOG2L, NTHR = L / E, NCH = E / V16, log2TPC = LOG2L - Log2<E>::value;
+    constexpr unsigned IMG = (unsigned)L * (unsigned)sizeof(cpx<T>);
     FFT_DYN_SMEM(smem);
     const int tid0 = FFT_TID;
     unsigned char* const land = smem;
@@ -61,13 +62,13 @@ FFT_KERNEL void FFT_WIDE_BOUNDS(LOG2L) wide_row_kernel(WideParams<T> p) {
     auto dma_row = [&](long long b) __attribute__((always_inline)) {
         int tid = tid0;
         FFT_OPAQUE(tid);
-        const cpx<T>* src = p.in + b * L + 2 * tid;
+        const cpx<T>* src = p.in + b * L + V16 * tid;
         if (p.nt & 1) {
             FFT_UNROLL
-            for (int i = 0; i < NCH; i++) FFT_DMA16_NT(src + i * 2 * NTHR, land, land_lds, (unsigned)(i * NTHR + tid) * 16u);
+            for (int i = 0; i < NCH; i++) FFT_DMA16_NT(src + i * V16 * NTHR, land, land_lds, (unsigned)(i * NTHR + tid) * 16u);
         } else {
             FFT_UNROLL
-            for (int i = 0; i < NCH; i++) FFT_DMA16(src + i * 2 * NTHR, land, land_lds, (unsigned)(i * NTHR + tid) * 16u);
+            for (int i = 0; i < NCH; i++) FFT_DMA16(src + i * V16 * NTHR, land, land_lds, (unsigned)(i * NTHR + tid) * 16u);
         }
     };
     const long long stride = FFT_NBLOCKS;
@@ -83,7 +84,7 @@ FFT_KERNEL void FFT_WIDE_BOUNDS(LOG2L) wide_row_kernel(WideParams<T> p) {
         int tid = tid0;
         FFT_OPAQUE(tid);
         cpx<T> x[1][E][1];
-        team_all_stages<T, E, true>(x, land, work, tw, tid, 0, 0, log2TPC, LOG2L, [&](int s, int) {
+        team_all_stages<T, E, (sizeof(T) == 4)>(x, land, work, tw, tid, 0, 0, log2TPC, LOG2L, [&](int s, int) {
             if (!INPLACE && s == 0 && b + stride < p.nb) dma_row(b + stride);  // the landing image is free: the next row flies under the stages
         }, p.inverse != 0);
         if (INPLACE && b + stride < p.nb) {
@@ -98,16 +99,28 @@ FFT_KERNEL void FFT_WIDE_BOUNDS(LOG2L) wide_row_kernel(WideParams<T> p) {
             FFT_UNROLL
             for (int e = 0; e < E; e++) x[0][e][0] = cscale(x[0][e][0], p.scale);
         }
-        // slot e holds X[tid + (L / 16) e]: the lanes of frequencies tid, tid ^ 1 pair up for 16-byte stores
-        const bool odd = (tid & 1) != 0;
-        cpx<T>* const dst0 = p.out + b * L + (tid & ~1);
-        FFT_UNROLL
-        for (int q = 0; q < E / 2; q++) {
-            vec16<T> v;
-            pair_rows<T>(x[0][2 * q][0], x[0][2 * q + 1][0], odd, 1, v);
-            vec16<T>* const dst = reinterpret_cast<vec16<T>*>(dst0 + ((2 * q + (odd ? 1 : 0)) << log2TPC));
-            if (p.nt & 2) FFT_STORE16_NT(dst, v);
-            else *dst = v;
+        // slot e holds X[tid + (L / E) e].  fp32: the lanes of frequencies tid, tid ^ 1 pair up for 16-byte stores
+        if constexpr (V16 == 2) {
+            const bool odd = (tid & 1) != 0;
+            cpx<T>* const dst0 = p.out + b * L + (tid & ~1);
+            FFT_UNROLL
+            for (int q = 0; q < E / 2; q++) {
+                vec16<T> v;
+                pair_rows<T>(x[0][2 * q][0], x[0][2 * q + 1][0], odd, 1, v);
+                vec16<T>* const dst = reinterpret_cast<vec16<T>*>(dst0 + ((2 * q + (odd ? 1 : 0)) << log2TPC));
+                if (p.nt & 2) FFT_STORE16_NT(dst, v);
+                else *dst = v;
+            }
+        } else {
+            cpx<T>* const dst0 = p.out + b * L + tid;
+            FFT_UNROLL
+            for (int e = 0; e < E; e++) {
+                vec16<T> v;
+                v.c[0] = x[0][e][0];
+                vec16<T>* const dst = reinterpret_cast<vec16<T>*>(dst0 + (e << log2TPC));
+                if (p.nt & 2) FFT_STORE16_NT(dst, v);
+                else *dst = v;
+            }
         }
     }
 }
