@@ -17,6 +17,12 @@ n1 in [r N1/G, (r+1) N1/G) of the N1 x N2 matrix A[n1][n2] = x[n1 N2 + n2].
   5. batched FFT of length N2 over n2 (batch N1/G)             -> C[k1][k2] = X[k1 + N1 k2]
   6. (natural_order=True) all-to-all: rank r ends up with the contiguous slab X[r N/G : (r+1) N/G]
 The inverse runs the same steps with conjugate twiddles and inverse local transforms (each scaled by 1/length: 1/N overall).
+
+ONE all-to-all (round 3; SURVEY.md 8f item 4: "one all-to-all between the passes"): steps 1 and 6 only re-distribute the
+contiguous slabs a caller usually holds.  A caller that keeps the signal distributed BY COLUMNS (transposed_in=True: rank r holds
+A[:, r N2/G : (r+1) N2/G] as a contiguous [N2/G][N1] array -- FFTW-MPI's TRANSPOSED_IN) and accepts C[k1][k2] = X[k1 + N1 k2]
+distributed by k1 (natural_order=False: TRANSPOSED_OUT) runs steps 2-5: two local passes and the ONE exchange between them.  A
+forward transform followed by an inverse one of the other orientation (convolutions, spectral filters) never needs the other two.
 """
 import math
 
@@ -42,7 +48,7 @@ class DistributedFFT1D:
     """local_fft(t, direction): batched 1D transform of a contiguous [batch, length] complex tensor on this rank's device,
     returning a tensor of the same shape.  On the GPU: `engine_local_fft` below (fftlib plans, cached per shape)."""
 
-    def __init__(self, n, local_fft, group=None, natural_order=True):
+    def __init__(self, n, local_fft, group=None, natural_order=True, transposed_in=False):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -50,10 +56,13 @@ class DistributedFFT1D:
         self.n1, self.n2 = _split(n, self.world)
         self.local_fft = local_fft
         self.natural_order = natural_order
+        self.transposed_in = transposed_in
+        self.all_to_alls = 0  # exchanges of the last call (tests: 1 with transposed_in and natural_order=False, else 2 or 3)
         self._tw = {}
 
     def _all_to_all(self, t):
         """t: [G, chunk...] -> received [G, chunk...]: slice g goes to rank g (dist.all_to_all_single)."""
+        self.all_to_alls += 1
         if self.world == 1:
             return t
         out = torch.empty_like(t)
@@ -76,11 +85,15 @@ class DistributedFFT1D:
         """x_local: this rank's slab, a contiguous complex tensor of N / G elements.  Returns this rank's slab of the
         spectrum (natural_order) or its [N1/G][N2] block of C[k1][k2] = X[k1 + N1 k2]."""
         g, n1, n2 = self.world, self.n1, self.n2
-        a = x_local.reshape(n1 // g, g, n2 // g)                     # [my n1][dest rank][its n2]
-        send = a.permute(1, 0, 2).contiguous()                       # [dest][my n1][its n2]
-        recv = self._all_to_all(send)                                # [src][src's n1][my n2]
-        cols = recv.reshape(n1, n2 // g).t().contiguous()            # [my n2][n1]: whole columns, contiguous
-        b = self.local_fft(cols, direction)                          # [my n2][k1]
+        self.all_to_alls = 0
+        if self.transposed_in:
+            cols = x_local.reshape(n2 // g, n1)                      # the caller holds whole columns: [my n2][n1]
+        else:
+            a = x_local.reshape(n1 // g, g, n2 // g)                 # [my n1][dest rank][its n2]
+            send = a.permute(1, 0, 2).contiguous()                   # [dest][my n1][its n2]
+            recv = self._all_to_all(send)                            # [src][src's n1][my n2]
+            cols = recv.reshape(n1, n2 // g).t().contiguous()        # [my n2][n1]: whole columns, contiguous
+        b = self.local_fft(cols.contiguous(), direction)             # [my n2][k1]
         b = b * self._twiddle(direction, b.device, b.dtype)
         send = b.reshape(n2 // g, g, n1 // g).permute(1, 0, 2).contiguous()   # [dest][my n2][its k1]
         recv = self._all_to_all(send)                                # [src][src's n2][my k1]
@@ -104,12 +117,14 @@ def engine_local_fft(t, direction):
     batch, n = t.shape
     dt = np.complex64 if t.dtype == torch.complex64 else np.complex128
     key = (n, batch, direction, dt, t.device.index)
-    if key not in _plans:
-        p = fftlib.Plan(n, batch, direction, dt)
-        # torch's default stream has handle 0, which the C ABI reads as "the plan's own stream": name the legacy default
-        # stream explicitly (hipStreamLegacy = 1), or the transform would race with torch's kernels around it
-        p.set_stream(torch.cuda.current_stream(t.device).cuda_stream or fftlib.HIP_STREAM_LEGACY)
-        _plans[key] = p
-    out = torch.empty_like(t)
-    _plans[key].execute_ptr(t.data_ptr(), out.data_ptr())
+    with torch.cuda.device(t.device):  # the plan lives on the TENSOR's device, not on whatever device is current
+        fftlib.set_device(t.device.index)
+        if key not in _plans:
+            _plans[key] = fftlib.Plan(n, batch, direction, dt)
+        # every call: torch's CURRENT stream of that device (a later call may run under another stream).  Handle 0 -- torch's
+        # default stream -- would mean "the plan's own stream" to the C ABI: name the legacy default stream explicitly
+        # (hipStreamLegacy = 1), or the transform would race with torch's kernels around it
+        _plans[key].set_stream(torch.cuda.current_stream(t.device).cuda_stream or fftlib.HIP_STREAM_LEGACY)
+        out = torch.empty_like(t)
+        _plans[key].execute_ptr(t.data_ptr(), out.data_ptr())
     return out

@@ -139,6 +139,12 @@ EXP_LIB_PATH = os.path.join(HERE, "libfft_mi355x_exp.so")  # -DFFT_EXPERIMENTS b
 OPT_TEAM_FORCE_FALLBACK, OPT_TEAM_ENABLE, OPT_NO_FUSION, OPT_NO_CHAIN = 1, 2, 3, 4
 
 
+def set_device(index):
+    """Make `index` the device new plans and buffers live on (fft_gpu_set_device; an 8-GPU process sets each in turn)."""
+    if load().fft_gpu_set_device(int(index)) != 0:
+        raise RuntimeError("fft_gpu_set_device(%d) failed" % index)
+
+
 def set_policy(team=-1, min_batch=-1, chunk_mb=-1):
     """Planner policy for plans created from now on (fft_gpu_set_policy_hip); -1 keeps a value."""
     load().fft_gpu_set_policy_hip(team, min_batch, chunk_mb)

@@ -59,6 +59,21 @@ WORKER = textwrap.dedent('''
                 err = float(np.linalg.norm(got - ref) / np.linalg.norm(ref))
                 worst = max(worst, err / (3e-6 if dtype == np.complex64 else 1e-11))
                 ok &= err < (3e-6 if dtype == np.complex64 else 1e-11)
+            # ONE all-to-all: the signal is held by columns (transposed in), the spectrum is left as C[k1][k2] (transposed out)
+            f = DistributedFFT1D(n, emu_local, natural_order=False, transposed_in=True)
+            a = x.reshape(f.n1, f.n2)
+            mine = np.ascontiguousarray(a[:, rank * f.n2 // world:(rank + 1) * f.n2 // world].T)      # [my n2][n1]
+            y = f(torch.from_numpy(mine), direction)
+            ok &= f.all_to_alls == 1
+            parts = [torch.empty_like(y) for _ in range(world)]
+            dist.all_gather(parts, y.contiguous())
+            c = torch.cat(parts, dim=0).numpy()
+            got = np.empty(n, dtype=c.dtype)
+            k1, k2 = np.meshgrid(np.arange(f.n1), np.arange(f.n2), indexing="ij")
+            got[(k1 + f.n1 * k2).reshape(-1)] = c.reshape(-1)
+            err = float(np.linalg.norm(got - ref) / np.linalg.norm(ref))
+            worst = max(worst, err / (3e-6 if dtype == np.complex64 else 1e-11))
+            ok &= err < (3e-6 if dtype == np.complex64 else 1e-11)
     if rank == 0:
         print(json.dumps({"ok": bool(ok), "worst": worst, "world": world}))
     dist.barrier()
