@@ -135,3 +135,67 @@ def test_one_transform_through_the_engine_on_the_device(tmp_path):
     script.write_text(GPU_WORKER % {"root": ROOT})
     out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr[-3000:]
+
+
+NCCL_WORKER = textwrap.dedent('''
+    import os, sys, json
+    import numpy as np
+    import torch, torch.distributed as dist
+    sys.path.insert(0, os.path.join(%(root)r, "tests"))
+    sys.path.insert(0, os.path.join(%(root)r, "fft-implementation-in-c_amd"))
+    import oracle_lib as O
+    from dist_fft import DistributedFFT1D, engine_local_fft
+    local = int(os.environ["LOCAL_RANK"])
+    torch.cuda.set_device(local)
+    dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+    rank, world = dist.get_rank(), dist.get_world_size()
+    ok = True
+    for n, dtype in ((1 << 22, np.complex64), (1 << 20, np.complex128)):
+        x = O.gen_lcg(n, 11, 1)[0].astype(dtype)
+        ref = {d: O.oracle_fft(x.astype(np.complex128), d, "exact") for d in (-1, 1)}
+        slab = torch.from_numpy(x[rank * n // world:(rank + 1) * n // world].copy()).cuda()
+        for d in (-1, 1):
+            f = DistributedFFT1D(n, engine_local_fft)             # slabs in, slabs out: three all-to-alls over RCCL
+            y = f(slab, d)
+            parts = [torch.empty_like(y) for _ in range(world)]
+            dist.all_gather(parts, y.contiguous())
+            got = torch.cat([p.reshape(-1) for p in parts]).cpu().numpy()
+            ok &= float(np.linalg.norm(got - ref[d]) / np.linalg.norm(ref[d])) < (3e-6 if dtype == np.complex64 else 1e-11)
+            f = DistributedFFT1D(n, engine_local_fft, natural_order=False, transposed_in=True)   # ONE all-to-all
+            a = x.reshape(f.n1, f.n2)
+            mine = torch.from_numpy(np.ascontiguousarray(a[:, rank * f.n2 // world:(rank + 1) * f.n2 // world].T)).cuda()
+            c = f(mine, d)
+            ok &= f.all_to_alls == 1
+            parts = [torch.empty_like(c) for _ in range(world)]
+            dist.all_gather(parts, c.contiguous())
+            cc = torch.cat(parts, dim=0).cpu().numpy()
+            got = np.empty(n, dtype=cc.dtype)
+            k1, k2 = np.meshgrid(np.arange(f.n1), np.arange(f.n2), indexing="ij")
+            got[(k1 + f.n1 * k2).reshape(-1)] = cc.reshape(-1)
+            ok &= float(np.linalg.norm(got - ref[d]) / np.linalg.norm(ref[d])) < (3e-6 if dtype == np.complex64 else 1e-11)
+    torch.cuda.synchronize()
+    if rank == 0:
+        print(json.dumps({"ok": bool(ok), "world": world}))
+    dist.barrier()
+    dist.destroy_process_group()
+''')
+
+
+@pytest.mark.gpu
+def test_one_transform_over_two_gpus_rccl(tmp_path):
+    """The multi-rank hardware path (VERDICT r2 item 7): two ranks, backend nccl (= RCCL), the engine's plans for the local
+    passes, slabs in / slabs out and the one-all-to-all form.  The ranks are started as fresh torch.distributed.run children
+    (nothing in THIS process touches a GPU); skipped where fewer than two devices are visible (this pool: one per box)."""
+    import json
+    import torch
+    if torch.cuda.device_count() < 2:  # (counting devices does not initialise the GPU on this image)
+        pytest.skip("needs two GPUs")
+    script = tmp_path / "nccl_worker.py"
+    script.write_text(NCCL_WORKER % {"root": ROOT})
+    env = dict(os.environ, PYTHONPATH=ROOT, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(free_port()), str(script)],
+                         capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    r = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert r["ok"] and r["world"] == 2, r
