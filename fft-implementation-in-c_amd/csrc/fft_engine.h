@@ -923,7 +923,9 @@ class Pow2Plan {
             if (prefer_chain && algo_ == ALGO_AUTO && !tables_only && (mirror || ends_chainable(passes.front(), passes.back()))) scratch2 = (cpx<T>*)rt->dmalloc(scratch_bytes);
         }
         if (algo_ == ALGO_AUTO && !wants_hooks && !tables_only) build_wide();
-        if (passes.size() > 1 && algo_ == ALGO_AUTO && !tables_only) {
+        // (plans whose owner fuses element-wise work into the ends -- Bluestein, the fused consumers -- never launch a team kernel:
+        // execute_hooked / _chain / _round run the multi-pass kernels; they do not hold its tables and windows either)
+        if (passes.size() > 1 && algo_ == ALGO_AUTO && !tables_only && !wants_hooks) {
             build_team_quad(batch);
             if (!team.ok) build_team(batch);
             if (team.ok && !team_geometry_is_built()) {

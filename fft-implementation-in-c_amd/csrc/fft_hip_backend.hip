@@ -578,6 +578,7 @@ fft_gpu_plan_t fft_gpu_plan_1d_ex_hip(int n, int batch, fft_direction dir, fft_p
         delete p;
         return NULL;
     }
+    __atomic_fetch_add(&g_count_streams, 1ll, __ATOMIC_RELAXED);  // (fft_gpu_debug_counters_hip: every stream the backend creates)
     const DeviceInfo* di = device_info(dev);
     if (!di) {
         fft_gpu_destroy_plan_hip(p);

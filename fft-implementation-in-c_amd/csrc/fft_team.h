@@ -143,17 +143,28 @@ FFT_DEVICE void team_form(const TeamParams<T>& p, unsigned* sh) {
         }
         FFT_SLEEP();
     }
+    unsigned xcc_rank = 0;  // my XCD's place among the XCDs the launch landed on
     if (ok) {  // every workgroup has registered: the per-XCD counts are final and the same for every reader
+        // exactly n_xcc XCC ids must hold a full set of seats and no other id any workgroup.  WHICH ids is the hardware's
+        // business: a partition of the device (DPX / QPX / CPX) need not number its XCDs from 0, so a team is
+        // numbered by the RANK of its XCC id among the ids present, not by the id itself.
+        int full = 0;
         for (int x = 0; x < 16; x++) {
             const unsigned cnt = FFT_ATOMIC_LOAD_AGENT(&p.ctl[TEAM_CTL_COUNT + 32 * x]);
-            if (cnt != (x < p.n_xcc ? (1u << p.log2seats) : 0u)) ok = 0;
+            if (cnt == (1u << p.log2seats)) {
+                full++;
+                if ((unsigned)x < xcc) xcc_rank++;
+            } else if (cnt != 0u) {
+                ok = 0;
+            }
         }
+        if (full != p.n_xcc) ok = 0;
     }
     if (p.force_no_teams) ok = 0;
     if (!ok && FFT_ATOMIC_CAS_AGENT(&p.ctl[TEAM_CTL_STATUS], 0u, (unsigned)TEAM_STATUS_NO_TEAMS) == 0u)
         FFT_ATOMIC_ADD_AGENT(&p.sticky[TEAM_STICKY_FALLBACKS], 1u);  // once per launch
     sh[0] = slot;
-    sh[1] = xcc;
+    sh[1] = xcc_rank;
     sh[2] = ok;
     sh[3] = 0;  // set when a team wait timed out: later waits return at once, the status word tells the host
 }
