@@ -288,48 +288,51 @@ class Pow2Plan {
         }
     }
 
-    // ---- team_quad_kernel (fft_team_quad.h): n = L x L, L = 4 M, M = E R2 (E values per thread and chunk, a radix-E and a radix-R2
-    // stage), teams of TS = L R2 / threads seats.  Device (512 threads, E = 16): n = 2^20 (R2 16, teams of 32), 2^18 (R2 8, teams of
-    // 8), 2^16 (R2 4, teams of 2); emulation (E = 4): n = 2^12 (R2 4) and 2^10 (R2 2).  Tables [W_n^x, x < L/2 | W_L^y, y < L |
-    // W_n^(L/2)]; window: 2 slots of TS images per team.
-    static constexpr int quad_E(int log2n_) { return (log2n_ == 20 || log2n_ == 18 || log2n_ == 16) ? 16 : (log2n_ == 12 || log2n_ == 10) ? 4 : 0; }
+    // ---- team_quad_kernel (fft_team_quad.h): n = L1 x L2 (L1 >= L2), L1 = 4 E RA, L2 = 4 E RB (E values per thread and chunk, a
+    // radix-E and a radix-RA / RB stage), teams of TS = L2 RA / threads seats.  Device (512 threads, E = 16): n = 2^20 (RA RB 16 16,
+    // teams of 32), 2^19 (16 8, 16), 2^18 (8 8, 8), 2^17 (8 4, 4), 2^16 (4 4, 2); emulation (E = 4): n = 2^12 (4 4), 2^11 (4 2)
+    // and 2^10 (2 2).  Tables [W_n^x, x < L2/2 | W_L1^y, y < L1 | W_L2^y, y < L2 | W_n^(L2/2)]; window: 2 slots of TS images per team.
+    static constexpr int quad_E(int log2n_) { return (log2n_ >= 16 && log2n_ <= 20) ? 16 : (log2n_ >= 10 && log2n_ <= 12) ? 4 : 0; }
     void build_team_quad(int batch) {
         const int mode = rt->policy.team_mode;
-        if (mode <= 0 || SZ != 8 || (log2n & 1)) return;
+        if (mode <= 0 || SZ != 8) return;
         const int E = quad_E(log2n);
         if (!E || !rt->team_quad(SZ, log2n)) return;
         TeamDesc<T> d;
         if (!rt->team_geometry(d.log2seats, d.n_xcc, d.nthreads)) return;
-        const int log2L = log2n / 2;
-        const long long L = 1ll << log2L;
-        const long long R2 = L / 4 / E;
-        if (R2 < 2 || R2 > E || R2 * E * 4 != L) return;
-        const int log2TE = log2L - 2 + ilog2(d.nthreads) - ilog2(R2);  // values of a chunk image: M rows x (threads / R2) columns
+        const int log2L1 = (log2n + 1) / 2, log2L2 = log2n / 2;
+        const long long L1 = 1ll << log2L1, L2 = 1ll << log2L2;
+        const long long RA = L1 / 4 / E, RB = L2 / 4 / E;
+        if (RB < 2 || RA > E || RA * E * 4 != L1 || RB * E * 4 != L2) return;
+        const int log2TE = log2L1 - 2 + ilog2(d.nthreads) - ilog2(RA);  // values of a chunk image: MA rows x (threads / RA) columns
         d.log2TS = log2n - 2 - log2TE;
         if (d.log2TS < 1 || d.log2TS > d.log2seats) return;
-        const long long NC = L >> d.log2TS;
-        if (NC * R2 != d.nthreads || NC < 8 || NC > 2 * (L / 4)) return;
+        const long long NC = L2 >> d.log2TS, NR = L1 >> d.log2TS;
+        if (NC * RA != d.nthreads || NR * RB != d.nthreads || NC < 8 || NR > 2 * (L1 / 4)) return;
 #if !defined(FFT_EMU)
-        if (!((log2n == 20 && d.log2TS == 5) || (log2n == 18 && d.log2TS == 3) || (log2n == 16 && d.log2TS == 1))) return;  // the device instantiations
+        if (d.log2TS != (log2n == 20 ? 5 : log2n == 19 ? 4 : log2n == 18 ? 3 : log2n == 17 ? 2 : 1)) return;  // the device instantiations
 #else
-        if (!((log2n == 12 && d.log2TS == 2) || (log2n == 10 && (d.log2TS == 1 || d.log2TS == 2)))) return;  // the emulation's
+        if (!((log2n == 12 && d.log2TS == 2) || ((log2n == 11 || log2n == 10) && (d.log2TS == 1 || d.log2TS == 2)))) return;  // the emulation's
 #endif
         if (mode == 1 && !rt->team_default_on(SZ, log2n)) return;
         d.quad = true;
         d.E = E;
         d.NT = 4;
-        d.log2L1 = d.log2L2 = log2L;
+        d.log2L1 = log2L1;
+        d.log2L2 = log2L2;
         d.n_teams = d.n_xcc << (d.log2seats - d.log2TS);
         if (d.n_teams > fftk::TEAM_CTL_MAX_TEAMS) return;
         d.data_bytes = 2 * (SZ << log2TE);
-        d.tables_elems = (int)(L / 2 + L);  // what the kernel keeps in LDS: [W_n^x, x < L/2 | W_L^y, y < L]; W_n^(L/2) follows in the blob
+        d.tables_elems = (int)(L2 / 2 + L1 + L2);  // what the kernel keeps in LDS; W_n^(L2/2) follows in the blob
         d.smem_bytes = d.data_bytes + d.tables_elems * SZ + 16;
         if (d.smem_bytes > rt->max_lds_bytes()) return;
         std::vector<cpx<T>> blob, part;
-        make_twiddle_table<T>(blob, L * L, L / 2, 1);
-        make_twiddle_table<T>(part, L, L, 1);
+        make_twiddle_table<T>(blob, L1 * L2, L2 / 2, 1);
+        make_twiddle_table<T>(part, L1, L1, 1);
         blob.insert(blob.end(), part.begin(), part.end());
-        make_twiddle_table<T>(part, L * L, 2, L / 2);
+        make_twiddle_table<T>(part, L2, L2, 1);
+        blob.insert(blob.end(), part.begin(), part.end());
+        make_twiddle_table<T>(part, L1 * L2, 2, L2 / 2);
         blob.push_back(part[1]);
         blob.push_back(part[0]);  // (pad to 16 bytes)
         d.scratch_bytes = ((size_t)SZ << (log2TE + d.log2TS)) * 2 * (size_t)d.n_teams;  // two window slots per team (one used where the kernel is built with one)
@@ -347,7 +350,7 @@ class Pow2Plan {
         // n = 2^20 from 128 MiB per execute (117 vs 112 Gpoint/s at 16 transforms), 2^18 from 512 MiB (192 vs 169), 2^16 from 1 GiB
         // (207 vs 185); and at least 4 transforms per team
         {
-            const long long mib = d.log2TS >= 5 ? 128 : d.log2TS == 3 ? 512 : 1024;
+            const long long mib = d.log2TS >= 5 ? 128 : d.log2TS >= 3 ? 512 : 1024;
             d.min_batch = mode == 1 ? (int)std::max<long long>(4ll * d.n_teams, (mib << 20) / ((long long)SZ << log2n)) : d.n_teams;
         }
         if (rt->policy.team_min_batch > 0) d.min_batch = rt->policy.team_min_batch;
@@ -359,16 +362,24 @@ class Pow2Plan {
     void launch_team_quad(const fftk::TeamParams<T>& tp) {
         const long long grid = (long long)team.n_xcc << team.log2seats;
         if constexpr (SZ == 8) {
+#define FFT_QUAD_GO(...) rt->launch_coresident(fftk::team_quad_kernel<T, __VA_ARGS__>, grid, team.nthreads, (size_t)team.smem_bytes, tp)
 #if defined(FFT_EMU)
-            if (log2n == 12) rt->launch_coresident(fftk::team_quad_kernel<T, 4, 2, 6, 2, 2>, grid, team.nthreads, (size_t)team.smem_bytes, tp);
-            else if (team.log2TS == 1) rt->launch_coresident(fftk::team_quad_kernel<T, 4, 1, 5, 1, 1>, grid, team.nthreads, (size_t)team.smem_bytes, tp);
-            else rt->launch_coresident(fftk::team_quad_kernel<T, 4, 1, 5, 2, 1>, grid, team.nthreads, (size_t)team.smem_bytes, tp);
+            if (log2n == 12) FFT_QUAD_GO(4, 2, 2, 6, 6, 2, 2);
+            else if (log2n == 11 && team.log2TS == 1) FFT_QUAD_GO(4, 2, 1, 6, 5, 1, 2);
+            else if (log2n == 11) FFT_QUAD_GO(4, 2, 1, 6, 5, 2, 1);
+            else if (team.log2TS == 1) FFT_QUAD_GO(4, 1, 1, 5, 5, 1, 1);
+            else FFT_QUAD_GO(4, 1, 1, 5, 5, 2, 1);
 #else
-            if (log2n == 20 && rt->team_quad_slots20() == 1) rt->launch_coresident(fftk::team_quad_kernel<T, 16, 4, 10, 5, 1>, grid, team.nthreads, (size_t)team.smem_bytes, tp);
-            else if (log2n == 20) rt->launch_coresident(fftk::team_quad_kernel<T, 16, 4, 10, 5, 2>, grid, team.nthreads, (size_t)team.smem_bytes, tp);
-            else if (log2n == 18) rt->launch_coresident(fftk::team_quad_kernel<T, 16, 3, 9, 3, 1>, grid, team.nthreads, (size_t)team.smem_bytes, tp);
-            else rt->launch_coresident(fftk::team_quad_kernel<T, 16, 2, 8, 1, 1>, grid, team.nthreads, (size_t)team.smem_bytes, tp);
+            const int slots = rt->team_quad_slots(log2n);
+            if (log2n == 20 && slots == 1) FFT_QUAD_GO(16, 4, 4, 10, 10, 5, 1);
+            else if (log2n == 20) FFT_QUAD_GO(16, 4, 4, 10, 10, 5, 2);
+            else if (log2n == 19 && slots == 1) FFT_QUAD_GO(16, 4, 3, 10, 9, 4, 1);
+            else if (log2n == 19) FFT_QUAD_GO(16, 4, 3, 10, 9, 4, 2);
+            else if (log2n == 18) FFT_QUAD_GO(16, 3, 3, 9, 9, 3, 1);
+            else if (log2n == 17) FFT_QUAD_GO(16, 3, 2, 9, 8, 2, 1);
+            else FFT_QUAD_GO(16, 2, 2, 8, 8, 1, 1);
 #endif
+#undef FFT_QUAD_GO
         }
         (void)grid;
     }

@@ -40,6 +40,9 @@ FFT_ROWS_FIXED8_LIST(FFT_EXTERN_FIXED8)
 #undef FFT_EXTERN_FIXED8
 }  // namespace fftk
 
+#ifndef FFT_QUAD_SLOTS19
+#define FFT_QUAD_SLOTS19 2
+#endif
 #include "fft_engine.h"
 #include "fft_plans_ext.h"
 
@@ -155,20 +158,18 @@ struct HipRT {
         static const int on = FFT_EXP_ENV("FFT_HIP_TEAM_PAIR") ? atoi(FFT_EXP_ENV("FFT_HIP_TEAM_PAIR")) : FFT_TEAM_PAIR_DEFAULT;
         return on && elem_bytes == 8 && (log2n == 19 || log2n == 20);
     }
-    // team_quad_kernel (fft_team_quad.h) instead of the tile-by-tile team kernels: fp32 n = 2^20.  FFT_HIP_TEAM_QUAD=0 (the
-    // experiments build) runs team_defer_kernel.
-    // team_quad_kernel (fft_team_quad.h) instead of the tile-by-tile team kernels: fp32 n = 2^20, 2^18, 2^16.  FFT_HIP_TEAM_QUAD (the
-    // experiments build): 0 never, 1 every built size (default), or a bit mask 2 = only 2^20, 4 = only 2^18, 8 = only 2^16
+    // team_quad_kernel (fft_team_quad.h) instead of the tile-by-tile team kernels: fp32 n = 2^16 .. 2^20.  FFT_HIP_TEAM_QUAD (the
+    // experiments build): 0 never, 1 every built size (default), or a bit mask: bit (log2n - 15) = that size only
     bool team_quad(int elem_bytes, int log2n) {
         static const int on = FFT_EXP_ENV("FFT_HIP_TEAM_QUAD") ? atoi(FFT_EXP_ENV("FFT_HIP_TEAM_QUAD")) : 1;
-        if (elem_bytes != 8 || !(log2n == 20 || log2n == 18 || log2n == 16)) return false;
+        if (elem_bytes != 8 || log2n < 16 || log2n > 20) return false;
         if (on <= 1) return on == 1;
-        return (on & (log2n == 20 ? 2 : log2n == 18 ? 4 : 8)) != 0;
+        return (on >> (log2n - 15)) & 1;
     }
-    // window slots of team_quad_kernel at n = 2^20 (the experiments build: FFT_HIP_QUAD_SLOTS20=1 runs the one-slot protocol)
-    int team_quad_slots20() {
-        static const int v = FFT_EXP_ENV("FFT_HIP_QUAD_SLOTS20") ? atoi(FFT_EXP_ENV("FFT_HIP_QUAD_SLOTS20")) : 2;
-        return v;
+    // window slots of team_quad_kernel where both protocols are built (n = 2^20, 2^19; the experiments build: FFT_HIP_QUAD_SLOTS=1 / 2)
+    int team_quad_slots(int log2n) {
+        static const int v = FFT_EXP_ENV("FFT_HIP_QUAD_SLOTS") ? atoi(FFT_EXP_ENV("FFT_HIP_QUAD_SLOTS")) : 0;
+        return v ? v : (log2n == 20 ? 2 : FFT_QUAD_SLOTS19);
     }
     // wide_row_kernel (fft_wide_row.h): single-pass n = 8192 and 16384 fp32.  FFT_HIP_WIDE=0 (the experiments build): the two-pass schedule
     bool wide_rows(int elem_bytes, int log2n) {

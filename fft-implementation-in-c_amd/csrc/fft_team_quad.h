@@ -59,15 +59,19 @@
 
 namespace fftk {
 
-template <int E, int LOG2R2, int LOG2L, int LOG2TS>
+// n = L1 x L2 (L1 rows j1 / k1, L2 columns j2 / k2), L1 = 4 MA, MA = E RA (the column step's sub-transforms), L2 = 4 MB, MB = E RB (the
+// row step's); a seat owns NC = L2 / TS columns and NR = L1 / TS rows; NC RA = NR RB threads.
+template <int E, int LOG2RA, int LOG2RB, int LOG2L1, int LOG2L2, int LOG2TS>
 struct QuadShape {
-    static constexpr int R2 = 1 << LOG2R2, G2 = E / R2, M = E * R2, L = 1 << LOG2L, TS = 1 << LOG2TS;
-    static constexpr int LOG2NC = LOG2L - LOG2TS, NC = 1 << LOG2NC;
-    static constexpr int NTHR = NC * R2;
-    static constexpr unsigned IMG = (unsigned)NC * M * 8u;  // bytes of one chunk image (fp32)
-    static constexpr int ILN = (64 / R2 < NC / 4) ? 64 / R2 : NC / 4;  // columns of a class per sender group (a wave on the device)
-    static_assert(L == 4 * M && R2 <= E && R2 >= 2, "L = 4 M, M = E R2: a radix-E and a radix-R2 stage");
-    static_assert(NC >= 8 && TS >= 2 && NC <= 2 * M, "four classes of at least two columns; a seat's rows span at most two row blocks");
+    static constexpr int RA = 1 << LOG2RA, RB = 1 << LOG2RB, GA = E / RA, GB = E / RB, MA = E * RA, MB = E * RB;
+    static constexpr int L1 = 1 << LOG2L1, L2 = 1 << LOG2L2, TS = 1 << LOG2TS;
+    static constexpr int LOG2NC = LOG2L2 - LOG2TS, NC = 1 << LOG2NC, LOG2NR = LOG2L1 - LOG2TS, NR = 1 << LOG2NR;
+    static constexpr int NTHR = NC * RA;
+    static constexpr unsigned IMG = (unsigned)NC * MA * 8u;  // bytes of one chunk image (fp32) = NR MB 8
+    static constexpr int ILN = (64 / RA < NC / 4) ? 64 / RA : NC / 4;  // columns of a class per sender group (a wave on the device)
+    static_assert(L1 == 4 * MA && L2 == 4 * MB && RA <= E && RA >= 2 && RB <= E && RB >= 2, "L = 4 M, M = E R: a radix-E and a radix-R stage");
+    static_assert(NC * RA == NR * RB, "both steps use every thread");
+    static_assert(NC >= 8 && TS >= 2 && NR <= 2 * MA, "four classes of at least two columns; a seat's rows span at most two row blocks");
 };
 
 // rotation of the column step's exchange image: the value of (row R, column c) sits at position (c + quad_phi(R / E)) mod NC
@@ -198,21 +202,22 @@ FFT_DEVICE void quad_twiddle_kb(cpx<T> (&x)[E], const cpx<T> (&v)[E], const cpx<
 // slot is rewritten in L2 (traffic 1.08 x), at the price of strict alternation -- write, everybody reads, write -- with eight
 // arrivals per transform and two team waits per round that sit on the critical path.  Measured (profiles/r3_ab_quad.txt): teams of 2
 // (n = 2^16) +6.5 % with one slot, teams of 8 (2^18) +-1 %, teams of 32 (2^20) -20 %.
-template <typename T, int E, int LOG2R2, int LOG2L, int LOG2TS, int SLOTS>
-FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2R2, LOG2L, LOG2TS) team_quad_kernel(TeamParams<T> p) {
+template <typename T, int E, int LOG2RA, int LOG2RB, int LOG2L1, int LOG2L2, int LOG2TS, int SLOTS>
+FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamParams<T> p) {
     constexpr bool QUAD_ONE_SLOT = SLOTS == 1;
     static_assert(SLOTS == 1 || SLOTS == 2, "one or two window slots");
     static_assert(vec16<T>::V == 2, "fp32: a 16-byte access holds the values of two adjacent rows");
-    using S = QuadShape<E, LOG2R2, LOG2L, LOG2TS>;
-    constexpr int L = S::L, TS = S::TS, M = S::M, NC = S::NC, LOG2NC = S::LOG2NC, NTHR = S::NTHR, R2 = S::R2, G2 = S::G2, ILN = S::ILN;
-    constexpr int LOG2M = LOG2L - 2;
+    using S = QuadShape<E, LOG2RA, LOG2RB, LOG2L1, LOG2L2, LOG2TS>;
+    constexpr int L1 = S::L1, L2 = S::L2, TS = S::TS, MA = S::MA, MB = S::MB, NC = S::NC, LOG2NC = S::LOG2NC, NR = S::NR, LOG2NR = S::LOG2NR;
+    constexpr int NTHR = S::NTHR, RA = S::RA, RB = S::RB, GA = S::GA, ILN = S::ILN;
+    constexpr int LOG2MA = LOG2L1 - 2;
     constexpr int LOG2ILN = Log2<ILN>::value;
     constexpr int NCH = E / 2;   // 16-byte pieces of a chunk image per thread
     constexpr int PPR = NC / 2;  // 16-byte pieces per image row
     constexpr int SZ = 8;
     constexpr unsigned IMG = S::IMG;
     constexpr size_t SLOT = (size_t)TS * IMG;  // one window slot: every seat's image of one round
-    constexpr long long n = (long long)L * L;
+    constexpr long long n = (long long)L1 * L2;
     static_assert(NTHR * NCH * 16 == (int)IMG && NTHR % PPR == 0, "a chunk image is NCH pieces per thread");
     FFT_DYN_SMEM(smem);
 
@@ -226,8 +231,9 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2R2, LOG2L, LOG2TS) team_quad_kernel(TeamPara
         vec16<T>* dst = reinterpret_cast<vec16<T>*>(tab_bytes);
         for (int i = tid; i < (p.tables_bytes >> 4); i += NTHR) dst[i] = src[i];
     }
-    const cpx<T>* const t0 = reinterpret_cast<const cpx<T>*>(tab_bytes);  // W_n^x, x < L / 2
-    const cpx<T>* const wl = t0 + L / 2;                                   // W_L^y, y < L (also W_n^(L y))
+    const cpx<T>* const t0 = reinterpret_cast<const cpx<T>*>(tab_bytes);  // W_n^x, x < L2 / 2
+    const cpx<T>* const wlA = t0 + L2 / 2;                                 // W_L1^y, y < L1 (also W_n^(L2 y))
+    const cpx<T>* const wlB = wlA + L1;                                    // W_L2^y, y < L2
     unsigned* const sh = reinterpret_cast<unsigned*>(tab_bytes + p.tables_bytes);  // [slot, xcc, ok, timed out]
 
     // ---- team formation (team_form, fft_team.h)
@@ -285,15 +291,15 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2R2, LOG2L, LOG2TS) team_quad_kernel(TeamPara
     //   ncol = t & (NC - 1), nr = t >> LOG2NC (< R2)
     // column-step stage 2 / sender map: a group (a wave on the device) = R2 values of g x ILN columns of ONE class ap = j2 mod 4
     //   g = t & (R2 - 1), il = (t >> LOG2R2) & (ILN - 1), grp = t >> (LOG2R2 + LOG2ILN): ap = grp & 3, cc = il + ILN (grp >> 2), c2 = ap + 4 cc
-    const int ap = FFT_UNIFORM((tid >> (LOG2R2 + LOG2ILN)) & 3);
-    auto sender_cc = [&](int t) __attribute__((always_inline)) { return ((t >> LOG2R2) & (ILN - 1)) + ILN * (t >> (LOG2R2 + LOG2ILN + 2)); };
+    const int ap = FFT_UNIFORM((tid >> (LOG2RA + LOG2ILN)) & 3);
+    auto sender_cc = [&](int t) __attribute__((always_inline)) { return ((t >> LOG2RA) & (ILN - 1)) + ILN * (t >> (LOG2RA + LOG2ILN + 2)); };
     // the block of M rows my row of the row step lies in (TS >= 4: the seat's; TS = 2: by the row -- a wave's on the device)
-    const int sigma = FFT_UNIFORM((NC * s + (tid & (NC - 1))) >> LOG2M);
-    const cpx<T> whalf = p.tables[L / 2 + L];  // W_n^(L/2), behind the two tables in the blob
-    auto wn = [&](unsigned x) __attribute__((always_inline)) {  // W_n^x = W_n^(x mod L/2) [* W_n^(L/2)] * W_L^(x / L)
-        const cpx<T> lo = cmul(t0[x & (L / 2 - 1)], wl[(x >> LOG2L) & (L - 1)]);
+    const int sigma = FFT_UNIFORM((NR * s + (tid & (NR - 1))) >> LOG2MA);
+    const cpx<T> whalf = p.tables[L2 / 2 + L1 + L2];  // W_n^(L2/2), behind the tables in the blob
+    auto wn = [&](unsigned x) __attribute__((always_inline)) {  // W_n^x = W_n^(x mod L2/2) [* W_n^(L2/2)] * W_L1^(x / L2)
+        const cpx<T> lo = cmul(t0[x & (L2 / 2 - 1)], wlA[(x >> LOG2L2) & (L1 - 1)]);
         const cpx<T> hi = cmul(lo, whalf);
-        return (x & (L / 2)) ? hi : lo;
+        return (x & (L2 / 2)) ? hi : lo;
     };
 
     auto in_of = [&](int it) __attribute__((always_inline)) { return p.in + (long long)(team + (long long)it * n_teams) * n; };
@@ -304,8 +310,8 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2R2, LOG2L, LOG2TS) team_quad_kernel(TeamPara
     auto dma_chunk = [&](const cpx<T>* inb, int a, int im) __attribute__((always_inline)) {
         int tid = tid0;
         FFT_OPAQUE(tid);
-        const cpx<T>* src = inb + ((long long)(4 * (tid / PPR) + a) << LOG2L) + NC * s + 2 * (tid % PPR);
-        constexpr long long step = (long long)(4 * (NTHR / PPR)) << LOG2L;
+        const cpx<T>* src = inb + ((long long)(4 * (tid / PPR) + a) << LOG2L2) + NC * s + 2 * (tid % PPR);
+        constexpr long long step = (long long)(4 * (NTHR / PPR)) << LOG2L2;
         const unsigned lds = img_lds0 + (unsigned)im * IMG;
         if (p.nt_mask & 1) {
             FFT_UNROLL
@@ -373,30 +379,30 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2R2, LOG2L, LOG2TS) team_quad_kernel(TeamPara
                 FFT_SCHED_BARRIER();
             };
             fine(0);  // 0: B1 passed
-            quad_stage1<T, E, R2, LOG2NC, LOG2L, true>(img, wl, t & (NC - 1), t >> LOG2NC, p.inverse != 0, fine);  // 1 reads landed, 2 dft, 3 twiddle
+            quad_stage1<T, E, RA, LOG2NC, LOG2L1, true>(img, wlA, t & (NC - 1), t >> LOG2NC, p.inverse != 0, fine);  // 1 reads landed, 2 dft, 3 twiddle
             fine(1);  // 4: writes done
             FFT_SYNC_LDS();
             fine(0);  // 5: B2 passed
             FFT_OPAQUE(t);
-            const int g = t & (R2 - 1), c2 = ap + 4 * sender_cc(t);
-            quad_stage2_read<T, E, LOG2NC>(v, img, quad_rot<R2, NC>(c2, g), g);
+            const int g = t & (RA - 1), c2 = ap + 4 * sender_cc(t);
+            quad_stage2_read<T, E, LOG2NC>(v, img, quad_rot<RA, NC>(c2, g), g);
             fine(1);  // 6: stage-2 reads landed
-            quad_stage2_dft<T, E, R2>(v);
+            quad_stage2_dft<T, E, RA>(v);
             fine(0);  // 7: dft
 #else
-            quad_stage1<T, E, R2, LOG2NC, LOG2L, true>(img, wl, t & (NC - 1), t >> LOG2NC, p.inverse != 0);
+            quad_stage1<T, E, RA, LOG2NC, LOG2L1, true>(img, wlA, t & (NC - 1), t >> LOG2NC, p.inverse != 0);
             FFT_SYNC_LDS();
             FFT_OPAQUE(t);
-            const int g = t & (R2 - 1), c2 = ap + 4 * sender_cc(t);
-            quad_stage2_read<T, E, LOG2NC>(v, img, quad_rot<R2, NC>(c2, g), g);
-            quad_stage2_dft<T, E, R2>(v);
+            const int g = t & (RA - 1), c2 = ap + 4 * sender_cc(t);
+            quad_stage2_read<T, E, LOG2NC>(v, img, quad_rot<RA, NC>(c2, g), g);
+            quad_stage2_dft<T, E, RA>(v);
 #endif
             if (a == 0) {
                 FFT_UNROLL
                 for (int k = 0; k < E; k++) blk[0][k] = v[k];
             } else {
                 // W_L^(a kb - M a ap): the class shift ap rotates the radix-4's OUTPUTS (block r = rows M (r - ap))
-                quad_twiddle_kb<T, E, R2, LOG2L>(blk[a], v, wl, a, g, -M * a * ap);
+                quad_twiddle_kb<T, E, RA, LOG2L1>(blk[a], v, wlA, a, g, -MA * a * ap);
             }
 #if QUAD_FINE_TRACE
             fine(0);  // 8: chunk twiddle
@@ -406,7 +412,7 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2R2, LOG2L, LOG2TS) team_quad_kernel(TeamPara
         auto send = [&](int r) __attribute__((always_inline)) {
             int t = tid0;
             FFT_OPAQUE(t);
-            const int g = t & (R2 - 1);
+            const int g = t & (RA - 1);
             const int q = (r - ap) & 3;
             unsigned char* const wslot = sbase + (size_t)(QUAD_ONE_SLOT ? 0 : (r & 1)) * SLOT;
             const int bprime = (NC / 4) * s + sender_cc(t);  // (j2 - ap) / 4: my column's place in its class
@@ -414,34 +420,34 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2R2, LOG2L, LOG2TS) team_quad_kernel(TeamPara
             for (int i = 0; i < E / 2; i++) {
                 vec16<T> v;
                 int k1;
-                if constexpr (G2 >= 2) {
-                    // two of my butterflies are adjacent rows: kb(g, j) and kb(g, j + R2)
-                    const int j = (i / R2) * 2 * R2 + (i % R2);
+                if constexpr (GA >= 2) {
+                    // two of my butterflies are adjacent rows: kb(g, j) and kb(g, j + RA)
+                    const int j = (i / RA) * 2 * RA + (i % RA);
                     v.c[0] = blk[r][j];
-                    v.c[1] = blk[r][j + R2];
-                    k1 = quad_kb<E, R2>(g, j) + M * q;
+                    v.c[1] = blk[r][j + RA];
+                    k1 = quad_kb<E, RA>(g, j) + MA * q;
                 } else {
                     const bool odd = (g & 1) != 0;
                     quad_pair<T>(blk[r][2 * i], blk[r][2 * i + 1], odd, v);  // even lane: rows (g, g + 1) of slot 2 i; odd lane: rows (g - 1, g) of slot 2 i + 1
-                    k1 = (g & ~1) + E * (2 * i + (odd ? 1 : 0)) + M * q;
+                    k1 = (g & ~1) + E * (2 * i + (odd ? 1 : 0)) + MA * q;
                 }
-                const int dst_seat = k1 >> LOG2NC, rho = k1 & (NC - 1);
-                *reinterpret_cast<vec16<T>*>(wslot + (size_t)dst_seat * IMG + (size_t)(((bprime << LOG2NC) + rho) * SZ)) = v;
+                const int dst_seat = k1 >> LOG2NR, rho = k1 & (NR - 1);
+                *reinterpret_cast<vec16<T>*>(wslot + (size_t)dst_seat * IMG + (size_t)(((bprime << LOG2NR) + rho) * SZ)) = v;
             }
         };
         // ---- combine: radix-4 over the chunks, then W_n^(k1 j2), k1 = kb + M q, q = (r - ap) mod 4 for block r
         {
             int t = tid0;
             FFT_OPAQUE(t);
-            const int g = t & (R2 - 1), c2 = ap + 4 * sender_cc(t);
+            const int g = t & (RA - 1), c2 = ap + 4 * sender_cc(t);
             const unsigned j2 = (unsigned)(NC * s + c2);  // my column of the transform
-            const cpx<T> f1 = wn((unsigned)M * j2), f2 = cmul(f1, f1), f3 = cmul(f2, f1);
-            cpx<T> base0[G2];  // W_n^((G2 g + i) j2)
-            base0[0] = wn((unsigned)(G2 * g) * j2);
-            if (G2 > 1) {
+            const cpx<T> f1 = wn((unsigned)MA * j2), f2 = cmul(f1, f1), f3 = cmul(f2, f1);
+            cpx<T> base0[GA];  // W_n^((GA g + i) j2)
+            base0[0] = wn((unsigned)(GA * g) * j2);
+            if (GA > 1) {
                 const cpx<T> u1 = wn(j2);
                 FFT_UNROLL
-                for (int i = 1; i < G2; i++) base0[i] = cmul(base0[i - 1], u1);
+                for (int i = 1; i < GA; i++) base0[i] = cmul(base0[i - 1], u1);
             }
             const cpx<T> sp = wn((unsigned)E * j2);
             FFT_UNROLL
@@ -458,11 +464,11 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2R2, LOG2L, LOG2TS) team_quad_kernel(TeamPara
                 const int q = (r - ap) & 3;  // wave-uniform
                 const cpx<T> fq = mk<T>(q == 0 ? (T)1 : q == 1 ? f1.re : q == 2 ? f2.re : f3.re, q == 0 ? (T)0 : q == 1 ? f1.im : q == 2 ? f2.im : f3.im);
                 FFT_UNROLL
-                for (int i = 0; i < G2; i++) {
-                    cpx<T> w[R2];
-                    quad_powers<T, R2>(w, cmul(base0[i], fq), sp);
+                for (int i = 0; i < GA; i++) {
+                    cpx<T> w[RA];
+                    quad_powers<T, RA>(w, cmul(base0[i], fq), sp);
                     FFT_UNROLL
-                    for (int k = 0; k < R2; k++) blk[r][i * R2 + k] = cmul(blk[r][i * R2 + k], w[k]);
+                    for (int k = 0; k < RA; k++) blk[r][i * RA + k] = cmul(blk[r][i * RA + k], w[k]);
                 }
                 if (r == 0) {
                     if (QUAD_ONE_SLOT) wait_all(G);  // the slot was last read in the previous transform's round 3: long true
@@ -505,22 +511,22 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2R2, LOG2L, LOG2TS) team_quad_kernel(TeamPara
             cpx<T>* img = reinterpret_cast<cpx<T>*>(img_b[r & 1]);
             int t = tid0;
             FFT_OPAQUE(t);
-            quad_stage1<T, E, R2, LOG2NC, LOG2L, false>(img, wl, t & (NC - 1), t >> LOG2NC, false);
+            quad_stage1<T, E, RB, LOG2NR, LOG2L2, false>(img, wlB, t & (NR - 1), t >> LOG2NR, false);
             if (r < 3) FFT_WAIT_VM0();  // my round-(r + 1) values are in L2
             FFT_SYNC_LDS();
             if (r < 3) arrive();  // S_(r+1)
             FFT_OPAQUE(t);
-            const int nr = t >> LOG2NC;
+            const int nr = t >> LOG2NR;
             cpx<T> v[E];
-            quad_stage2_read<T, E, LOG2NC>(v, img, t & (NC - 1), nr);
+            quad_stage2_read<T, E, LOG2NR>(v, img, t & (NR - 1), nr);
             if (r < 3) {
                 wait_all(G + 2 * r + 3);  // everybody's values of round r + 1 are in L2
                 ev();
                 dma_window(0, (r + 1) & 1);
             }
-            quad_stage2_dft<T, E, R2>(v);
+            quad_stage2_dft<T, E, RB>(v);
             const int apr = (r - sigma) & 3;  // the class this round delivered to my row
-            if (apr != 0) quad_twiddle_kb<T, E, R2, LOG2L>(zt[r], v, wl, apr, nr, 0);  // W_L^(apr kb): < 3 M
+            if (apr != 0) quad_twiddle_kb<T, E, RB, LOG2L2>(zt[r], v, wlB, apr, nr, 0);  // W_L2^(apr kb): < 3 MB
             else {
                 FFT_UNROLL
                 for (int k = 0; k < E; k++) zt[r][k] = v[k];
@@ -537,12 +543,12 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2R2, LOG2L, LOG2TS) team_quad_kernel(TeamPara
             cpx<T>* img = reinterpret_cast<cpx<T>*>(img_b[r & 1]);
             int t = tid0;
             FFT_OPAQUE(t);
-            quad_stage1<T, E, R2, LOG2NC, LOG2L, false>(img, wl, t & (NC - 1), t >> LOG2NC, false);
+            quad_stage1<T, E, RB, LOG2NR, LOG2L2, false>(img, wlB, t & (NR - 1), t >> LOG2NR, false);
             FFT_SYNC_LDS();
             FFT_OPAQUE(t);
-            const int nr = t >> LOG2NC;
+            const int nr = t >> LOG2NR;
             cpx<T> v[E];
-            quad_stage2_read<T, E, LOG2NC>(v, img, t & (NC - 1), nr);
+            quad_stage2_read<T, E, LOG2NR>(v, img, t & (NR - 1), nr);
             if (r < 3) {
                 // the next round's image is requested NOW (the other image was last read in round r - 1) and flies under this
                 // round's second stage; behind it the values of round r + 2, into the slot this round's image came from
@@ -552,25 +558,25 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2R2, LOG2L, LOG2TS) team_quad_kernel(TeamPara
                 dma_window((r + 1) & 1, (r + 1) & 1);
                 if (r < 2) send(r + 2);
             }
-            quad_stage2_dft<T, E, R2>(v);
+            quad_stage2_dft<T, E, RB>(v);
             const int apr = (r - sigma) & 3;  // the class this round delivered to my row
-            if (apr != 0) quad_twiddle_kb<T, E, R2, LOG2L>(zt[r], v, wl, apr, nr, 0);  // W_L^(apr kb): < 3 M
+            if (apr != 0) quad_twiddle_kb<T, E, RB, LOG2L2>(zt[r], v, wlB, apr, nr, 0);  // W_L2^(apr kb): < 3 MB
             else {
                 FFT_UNROLL
                 for (int k = 0; k < E; k++) zt[r][k] = v[k];
             }
         }
         }
-        // ---- final radix-4 over the rounds, modulation, transposed store: X[k1 + L k2], k1 = NC s + rho, k2 = kb + M ka; the
-        // lanes of rows rho, rho ^ 1 pair up so that every store is 16 bytes and every wave instruction writes whole NC-row
+        // ---- final radix-4 over the rounds, modulation, transposed store: X[k1 + L1 k2], k1 = NR s + rho, k2 = kb + MB ka; the
+        // lanes of rows rho, rho ^ 1 pair up so that every store is 16 bytes and every wave instruction writes whole NR-row
         // segments; the stores go out pair of values by pair of values between the butterflies
         ev();
         {
             int t = tid0;
             FFT_OPAQUE(t);
-            const int ncol = t & (NC - 1), nr = t >> LOG2NC;
+            const int ncol = t & (NR - 1), nr = t >> LOG2NR;
             const bool odd = (ncol & 1) != 0;
-            cpx<T>* const line0 = outb + NC * s + (ncol & ~1);
+            cpx<T>* const line0 = outb + NR * s + (ncol & ~1);
             FFT_UNROLL
             for (int i = 0; i < E / 2; i++) {
                 cpx<T> y[2][4];
@@ -589,8 +595,8 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2R2, LOG2L, LOG2TS) team_quad_kernel(TeamPara
                 for (int ka = 0; ka < 4; ka++) {
                     vec16<T> v;
                     quad_pair<T>(y[0][ka], y[1][ka], odd, v);
-                    const long long k2 = (odd ? quad_kb<E, R2>(nr, 2 * i + 1) : quad_kb<E, R2>(nr, 2 * i)) + M * ka;
-                    vec16<T>* const dst = reinterpret_cast<vec16<T>*>(line0 + (k2 << LOG2L));
+                    const long long k2 = (odd ? quad_kb<E, RB>(nr, 2 * i + 1) : quad_kb<E, RB>(nr, 2 * i)) + MB * ka;
+                    vec16<T>* const dst = reinterpret_cast<vec16<T>*>(line0 + (k2 << LOG2L1));
                     if (p.nt_mask & 2) FFT_STORE16_NT(dst, v);
                     else *dst = v;
                 }

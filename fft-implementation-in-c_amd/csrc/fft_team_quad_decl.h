@@ -8,19 +8,27 @@
 namespace fftk {
 
 #if defined(FFT_EMU)
-#define FFT_QUAD_BOUNDS(LOG2R2, LOG2L, LOG2TS)
+#define FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS)
 #else
-// NTHR = (L / TS) * R2 threads, all resident on one CU: NTHR / 256 waves per SIMD
-#define FFT_QUAD_BOUNDS(LOG2R2, LOG2L, LOG2TS) __launch_bounds__((((1 << (LOG2L)) >> (LOG2TS)) << (LOG2R2)), ((((1 << (LOG2L)) >> (LOG2TS)) << (LOG2R2))) / 256)
+// NTHR = (L2 / TS) * RA threads, all resident on one CU: NTHR / 256 waves per SIMD
+#define FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) __launch_bounds__((((1 << (LOG2L2)) >> (LOG2TS)) << (LOG2RA)), ((((1 << (LOG2L2)) >> (LOG2TS)) << (LOG2RA))) / 256)
 #endif
-template <typename T, int E, int LOG2R2, int LOG2L, int LOG2TS, int SLOTS>
-FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2R2, LOG2L, LOG2TS) team_quad_kernel(TeamParams<T> p);
+template <typename T, int E, int LOG2RA, int LOG2RB, int LOG2L1, int LOG2L2, int LOG2TS, int SLOTS>
+FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamParams<T> p);
 
 #if !defined(FFT_EMU)
-extern template __global__ void team_quad_kernel<float, 16, 4, 10, 5, 2>(TeamParams<float>);  // n = 2^20: M = 16 x 16, teams of 32 (a whole XCD), two window slots
-extern template __global__ void team_quad_kernel<float, 16, 4, 10, 5, 1>(TeamParams<float>);  // ... one (experiments)
-extern template __global__ void team_quad_kernel<float, 16, 3, 9, 3, 1>(TeamParams<float>);   // n = 2^18: M = 16 x 8, teams of 8, one window slot
-extern template __global__ void team_quad_kernel<float, 16, 2, 8, 1, 1>(TeamParams<float>);   // n = 2^16: M = 16 x 4, teams of 2, one window slot
+// <T, E, log2 RA, log2 RB, log2 L1, log2 L2, log2 TS, window slots>; the list of fft_team_quad.hip
+#define FFT_QUAD_INSTANCES(X)                                                                                         \
+    X(float, 16, 4, 4, 10, 10, 5, 2) /* n = 2^20: 1024 x 1024, teams of 32 (a whole XCD), two window slots */          \
+    X(float, 16, 4, 4, 10, 10, 5, 1) /* ... with one (experiments: FFT_HIP_QUAD_SLOTS=1; traffic 1.08 x, but -20 %) */ \
+    X(float, 16, 4, 3, 10, 9, 4, 2)  /* n = 2^19: 1024 x 512, teams of 16 */                                           \
+    X(float, 16, 4, 3, 10, 9, 4, 1)                                                                                    \
+    X(float, 16, 3, 3, 9, 9, 3, 1)   /* n = 2^18: 512 x 512, teams of 8, one window slot */                            \
+    X(float, 16, 3, 2, 9, 8, 2, 1)   /* n = 2^17: 512 x 256, teams of 4 */                                             \
+    X(float, 16, 2, 2, 8, 8, 1, 1)   /* n = 2^16: 256 x 256, teams of 2 */
+#define FFT_QUAD_EXTERN(T, ...) extern template __global__ void team_quad_kernel<T, __VA_ARGS__>(TeamParams<T>);
+FFT_QUAD_INSTANCES(FFT_QUAD_EXTERN)
+#undef FFT_QUAD_EXTERN
 #endif
 
 }  // namespace fftk
