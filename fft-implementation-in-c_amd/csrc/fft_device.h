@@ -60,6 +60,7 @@ inline T shfl_xor_any(T v, int mask) {
 #include <sched.h>
 #define FFT_XCC_ID(nteams) ((unsigned)((emu::blockIdx_.x + ((emu::xcc_skew && emu::blockIdx_.x == 0) ? 1u : 0u)) % (unsigned)(nteams)))
 #define FFT_ATOMIC_ADD_AGENT(p, v) __atomic_fetch_add((p), (v), __ATOMIC_SEQ_CST)
+#define FFT_ATOMIC_ADD_AGENT_RELAXED(p, v) __atomic_fetch_add((p), (v), __ATOMIC_SEQ_CST)
 #define FFT_ATOMIC_LOAD_AGENT(p) __atomic_load_n((p), __ATOMIC_SEQ_CST)
 #define FFT_ATOMIC_STORE_AGENT(p, v) __atomic_store_n((p), (v), __ATOMIC_SEQ_CST)
 namespace emu {
@@ -77,6 +78,8 @@ bool test_drop();   // test hook: this workgroup leaves right after the team has
 #define FFT_L2_FLAG_LOAD(p) __atomic_load_n((p), __ATOMIC_SEQ_CST)
 #define FFT_L2_COUNT_ADD(p) ((void)__atomic_fetch_add((p), 1u, __ATOMIC_SEQ_CST))
 #define FFT_L2_COUNT_POLL(p) __atomic_load_n((p), __ATOMIC_SEQ_CST)
+// the counter and the word behind it (read AFTER the counter): low half = counter, high half = that word
+#define FFT_L2_COUNT_POLL2(p) ((unsigned long long)__atomic_load_n((p), __ATOMIC_SEQ_CST) | ((unsigned long long)__atomic_load_n((p) + 1, __ATOMIC_SEQ_CST) << 32))
 #define FFT_LDS_FRESH() __atomic_thread_fence(__ATOMIC_SEQ_CST)
 #define FFT_SCHED_BARRIER() ((void)0)
 #define FFT_WAIT_VM0() __atomic_thread_fence(__ATOMIC_SEQ_CST)
@@ -160,6 +163,8 @@ __device__ __forceinline__ double fft_xor_exchange(double v, int mask, bool) { r
 #define FFT_XCC_ID(nteams) ((unsigned)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15u)
 // device-coherent (agent-scope) atomics: team formation and the status word only
 #define FFT_ATOMIC_ADD_AGENT(p, v) __hip_atomic_fetch_add((p), (v), __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT)
+// ... without ordering (no L2 write-back / invalidate around it): a counter that guards no data (team_quad_kernel's work claims)
+#define FFT_ATOMIC_ADD_AGENT_RELAXED(p, v) __hip_atomic_fetch_add((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define FFT_ATOMIC_LOAD_AGENT(p) __hip_atomic_load((p), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)
 #define FFT_ATOMIC_STORE_AGENT(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT)
 __device__ __forceinline__ unsigned fft_cas_agent(unsigned* p, unsigned expected, unsigned desired) {  // returns the value found
@@ -183,6 +188,15 @@ __device__ __forceinline__ unsigned fft_cas_agent(unsigned* p, unsigned expected
 __device__ __forceinline__ unsigned fft_scalar_load_glc(const unsigned* p) {
     unsigned v;
     asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+    return v;
+}
+// the counter and the word behind it in ONE 8-byte access (p 8-byte aligned): a value stored to that word before an arrival is seen by
+// every poll that sees the arrival -- a second load would cost a second L2 round trip on the critical path (scalar loads wait 1 - 4 us
+// behind a busy L2: profiles/r3_ab_dynamic.txt)
+#define FFT_L2_COUNT_POLL2(p) fft_scalar_load2_glc((const unsigned*)(p))
+__device__ __forceinline__ unsigned long long fft_scalar_load2_glc(const unsigned* p) {
+    unsigned long long v;
+    asm volatile("s_load_dwordx2 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
     return v;
 }
 // the next read of a (non-volatile) LDS word is a real ds_read: volatile accesses through a pointer whose address

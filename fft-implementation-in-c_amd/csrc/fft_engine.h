@@ -324,7 +324,7 @@ class Pow2Plan {
         if (d.n_teams > fftk::TEAM_CTL_MAX_TEAMS) return;
         d.data_bytes = 2 * (SZ << log2TE);
         d.tables_elems = (int)(L2 / 2 + L1 + L2);  // what the kernel keeps in LDS; W_n^(L2/2) follows in the blob
-        d.smem_bytes = d.data_bytes + d.tables_elems * SZ + 16;
+        d.smem_bytes = d.data_bytes + d.tables_elems * SZ + 32;  // + sh[8]: team slot, XCD, formed, timed out, next transform
         if (d.smem_bytes > rt->max_lds_bytes()) return;
         std::vector<cpx<T>> blob, part;
         make_twiddle_table<T>(blob, L1 * L2, L2 / 2, 1);
@@ -346,11 +346,11 @@ class Pow2Plan {
         }
         rt->memset_async(d.sticky, 0, fftk::TEAM_STICKY_WORDS * sizeof(unsigned));
         rt->h2d(d.tables, blob.data(), blob.size() * SZ);
-        // batch crossover against the multi-pass schedule (tools/batch_crossover.py 20,18,16; profiles/r3_batch_crossover.txt):
-        // n = 2^20 from 128 MiB per execute (117 vs 112 Gpoint/s at 16 transforms), 2^18 from 512 MiB (192 vs 169), 2^16 from 1 GiB
-        // (207 vs 185); and at least 4 transforms per team
+        // batch crossover against the multi-pass schedule (tools/batch_crossover.py; profiles/r3_batch_crossover.txt):
+        // n = 2^20 from 128 MiB per execute (117 vs 112 Gpoint/s at 16 transforms), 2^19 from 256 MiB (155 vs 133), 2^18 from 512 MiB
+        // (192 vs 169), 2^17 from 512 MiB (196 vs 177), 2^16 from 1 GiB (207 vs 185); and at least 4 transforms per team
         {
-            const long long mib = d.log2TS >= 5 ? 128 : d.log2TS >= 3 ? 512 : 1024;
+            const long long mib = d.log2TS >= 5 ? 128 : d.log2TS == 4 ? 256 : d.log2TS >= 2 ? 512 : 1024;
             d.min_batch = mode == 1 ? (int)std::max<long long>(4ll * d.n_teams, (mib << 20) / ((long long)SZ << log2n)) : d.n_teams;
         }
         if (rt->policy.team_min_batch > 0) d.min_batch = rt->policy.team_min_batch;
@@ -576,6 +576,9 @@ class Pow2Plan {
         tp.dma_split2 = dma_split2;
         static const int seat_rot = FFT_EXP_ENV("FFT_HIP_TEAM_SEAT_ROT") ? atoi(FFT_EXP_ENV("FFT_HIP_TEAM_SEAT_ROT")) : 0;
         tp.seat_rot = seat_rot;
+        // team_quad_kernel: transforms claimed team by team from a device-wide counter (the XCDs run 2 - 4 % apart; FFT_HIP_TEAM_DYNAMIC=0: static split)
+        const int dynamic = FFT_EXP_ENV("FFT_HIP_TEAM_DYNAMIC") ? atoi(FFT_EXP_ENV("FFT_HIP_TEAM_DYNAMIC")) : 1;
+        tp.dynamic = team.quad ? dynamic : 0;
         // measured (profiles/r2_ab_pair.txt): 4 for the plain kernels, 2 where the row tiles are paired
         static const int tile_rot = FFT_EXP_ENV("FFT_HIP_TEAM_TILE_ROT") ? atoi(FFT_EXP_ENV("FFT_HIP_TEAM_TILE_ROT")) : -1;
         tp.tile_rot = tile_rot >= 0 ? tile_rot : (team.pair ? 2 : 4);

@@ -50,6 +50,7 @@ namespace fftk {
 // control block (32-bit words), zeroed before every launch
 enum {
     TEAM_CTL_REGISTERED = 0,          // workgroups that have registered; TEAM_CTL_POISON set: formation was given up
+    TEAM_CTL_NEXT = 2,                // team_quad_kernel, dynamic: transforms claimed beyond the first of every team (the next unclaimed one is n_teams + this)
     TEAM_CTL_STATUS = 1,              // 0 = done by this kernel; 1 = teams could not be formed (nothing touched); 2 = barrier timeout
     TEAM_CTL_COUNT = 32,              // + 32 * xcc : workgroups registered on that XCD (own 128-byte line each)
     TEAM_CTL_FLAGS = 32 + 32 * 16,    // + 32 * team : the team's barrier line, one generation word per member
@@ -85,6 +86,7 @@ struct TeamParams {
     int nt_mask;              // cache policy: bit 0 column-tile DMA nt, bit 1 result stores nt, bit 2 window loads sc1 nt (read once)
     int force_no_teams;       // tests: pretend the placement check failed (exercises the two-pass fallback)
     int tile_rot;             // column_block(): seats rotate by this many blocks per tile
+    int dynamic;              // team_quad_kernel: 1 = a team claims its next transform from a device-wide counter (TEAM_CTL_NEXT) instead of team + it * n_teams
     int seat_rot;             // experiments: seat = (registration order + seat_rot) mod TS
     int dma_split, dma_split2;  // (unused: the landing DMA goes out in two halves, from slots 0 and 1 -- compile-time, so that the chunk loop folds)
     int ablate;               // experiments: 1 skip the inter-pass twiddle, 2 skip the stages, 4 no result stores, 8 no column-tile DMA

@@ -2,33 +2,34 @@
 // access a run of whole 128-byte lines (256-byte row segments at n = 2^20, 512 at 2^18, 1 KiB at 2^16), the exchange
 // between the two steps in four rounds through the XCD's L2.
 //
-// team_fft_kernel / team_defer_kernel (fft_team.h, fft_team_defer.h) cut a transform n = L x L into 64 KiB tiles of
+// team_fft_kernel / team_defer_kernel (fft_team.h, fft_team_defer.h) cut a transform n = L1 x L2 into 64 KiB tiles of
 // L rows x 8 columns: 64-byte row segments (n = 2^20), which a CU's memory pipeline streams at two thirds of the rate of
 // whole lines (profiles/r1e_membench4), three Stockham stages with two LDS exchanges per tile, and five team-wide
 // arrivals per transform with the column step's results handed over tile by tile.  Here a seat (workgroup, one per
-// CU) owns NC = L / TS ADJACENT columns in the column step and NC adjacent rows in the row step, i.e. 256 KiB of the
-// transform -- more than LDS holds, so both steps are decimated in time by 4 (the four-step split of
-// optimizations/parallel_fft.c:213-272 with each length-L transform itself split 4 x M, M = L / 4):
+// CU) owns NC = L2 / TS ADJACENT columns in the column step and NR = L1 / TS adjacent rows in the row step, i.e. n / TS
+// values (256 KiB) -- more than LDS holds, so both steps are decimated in time by 4 (the four-step split of
+// optimizations/parallel_fft.c:213-272 with the length-L1 and length-L2 transforms themselves split 4 x MA, 4 x MB):
 //
-//   column step, chunk a = 0..3: rows j1 = 4 b + a (b < M) of my NC columns land in LDS (LDS-DMA, 64 KiB, the next chunk
-//       flies meanwhile); length-M transforms as a radix-E and a radix-R2 stage (M = E R2, E = 16 values per thread, ONE
-//       LDS exchange, run in place); the results x W_L^(a kb) wait in registers (4 x E values per thread);
+//   column step, chunk a = 0..3: rows j1 = 4 b + a (b < MA) of my NC columns land in LDS (LDS-DMA, 64 KiB, the next chunk
+//       flies meanwhile); length-MA transforms as a radix-E and a radix-RA stage (MA = E RA, E = 16 values per thread, ONE
+//       LDS exchange, run in place); the results x W_L1^(a kb) wait in registers (4 x E values per thread);
 //   combine: radix-4 butterflies over a, thread-local, then the inter-step twiddle W_n^(k1 j2): the thread now holds
 //       X[k1][j2] for 4 E rows k1 of ONE column j2;
 //   exchange + row step, round r = 0..3: every seat writes a quarter of its values into the team's window in the
-//       XCD's L2 (2 slots of TS x 64 KiB, rewritten every other round), one team-wide arrival, every seat pulls its
-//       64 KiB image of the round -- the samples j2 = 4 b' + a' of ONE residue class a' for each of its NC rows -- into LDS
-//       (sc1 LDS-DMA), runs the length-M transforms and keeps the results;
-//   final: radix-4 over the classes, thread-local; all 4 E results of a thread go out as whole NC-row segments.
+//       XCD's L2 (2 slots of TS x 64 KiB, rewritten every other round -- or one, see SLOTS), one team-wide arrival, every
+//       seat pulls its 64 KiB image of the round -- the samples j2 = 4 b' + a' of ONE residue class a' for each of its NR rows --
+//       into LDS (sc1 LDS-DMA), runs the length-MB transforms (MB = E RB) and keeps the results;
+//   final: radix-4 over the classes, thread-local; all 4 E results of a thread go out as whole NR-row segments.
 //
-// Which class a row receives in round r rotates with the row's block q = k1 / M (a' = r - q mod 4) and which block of
+// Which class a row receives in round r rotates with the row's block q = k1 / MA (a' = r - q mod 4) and which block of
 // rows a sending wave serves rotates with the wave's own class: both rotations are absorbed by twiddle exponents (a
 // circular shift of a DFT's inputs / outputs is a modulation of its outputs / inputs), so every register index is a
-// compile-time constant and no code is specialised per wave.  Five arrivals per transform, four of them in the
-// exchange and never waited for on the spot; HBM traffic per transform: n in, n out.
+// compile-time constant and no code is specialised per wave.  Five arrivals per transform (eight with one slot), four of
+// them in the exchange and never waited for on the spot; HBM traffic per transform: n in, n out.
 //
-// Shapes (fft_team_quad.hip): n = 2^20 (E 16, R2 16, teams of 32), 2^18 (R2 8, teams of 8), 2^16 (R2 4, teams of 2);
-// the emulation runs E = 4 with R2 = 4 and R2 = 2.
+// Shapes (fft_team_quad_decl.h): n = 2^20 = 1024 x 1024 (RA = RB = 16, teams of 32), 2^19 = 1024 x 512 (16, 8; teams of 16),
+// 2^18 = 512 x 512 (8, 8; 8), 2^17 = 512 x 256 (8, 4; 4), 2^16 = 256 x 256 (4, 4; 2); the emulation runs E = 4 with
+// 64 x 64, 64 x 32 and 32 x 32.
 #pragma once
 
 #include "fft_team_quad_decl.h"
@@ -39,7 +40,9 @@
 // polls merged into stage barriers (-1.5 %), two-deep column prefetch (-1 %), result stores spread over the next column
 // step (-5 ... -15 %), a third window slot (-12 %: 6 MiB of window per XCD thrash the 4 MiB L2), two 256-thread
 // workgroups per CU with teams of 64 (-21 %), folding the final modulation into the last radix-4 (-0.7 %), other
-// cache-policy bits on the streams (+-0; without `nt` -7 %).
+// cache-policy bits on the streams (+-0; without `nt` -7 %), round 1's values sent behind the first team wait of the exchange instead
+// of behind a wait of their own in the combine (-2.5 %), the next transform's index read by every wave with a scalar load of its own in
+// round 3 (-10 %: 256 waves per XCD queue behind the result stores; the index now rides on the team wait's poll, see `pub`).
 #ifndef QUAD_LDS_SINGLE  // 1: the stage exchanges use single ds_read_b64 / ds_write_b64 (FFT_LDS_LD64 / ST64), never the fused forms (+5 %)
 #define QUAD_LDS_SINGLE 1
 #endif
@@ -234,10 +237,13 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
     const cpx<T>* const t0 = reinterpret_cast<const cpx<T>*>(tab_bytes);  // W_n^x, x < L2 / 2
     const cpx<T>* const wlA = t0 + L2 / 2;                                 // W_L1^y, y < L1 (also W_n^(L2 y))
     const cpx<T>* const wlB = wlA + L1;                                    // W_L2^y, y < L2
-    unsigned* const sh = reinterpret_cast<unsigned*>(tab_bytes + p.tables_bytes);  // [slot, xcc, ok, timed out]
+    unsigned* const sh = reinterpret_cast<unsigned*>(tab_bytes + p.tables_bytes);  // [slot, xcc, ok, timed out, next transform + 1]
 
     // ---- team formation (team_form, fft_team.h)
-    if (tid == 0) team_form(p, sh);
+    if (tid == 0) {
+        sh[4] = 0;
+        team_form(p, sh);
+    }
     FFT_SYNC();
     FFT_LDS_FRESH();
     if (!sh[2]) return;
@@ -245,8 +251,7 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
     const int s = (int)(seat & (unsigned)(TS - 1));  // my seat in the team
     const int team = (int)((FFT_UNIFORM(sh[1]) << (p.log2seats - LOG2TS)) + (seat >> LOG2TS));
     const int n_teams = p.n_xcc << (p.log2seats - LOG2TS);
-    const int NTR = team < p.nb ? (p.nb - team + n_teams - 1) / n_teams : 0;  // transforms of this team
-    if (NTR == 0) return;
+    if (team >= p.nb) return;  // more teams than transforms
     if (FFT_TEST_DROP()) return;  // emulation only: a member that never arrives
 
     unsigned char* const sbase = p.scratch + (size_t)team * SLOTS * SLOT;
@@ -264,12 +269,19 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
 
     // everybody has made arrival number g <=> the team's counter >= TS * g (nobody makes arrival g + 1 before everybody has
     // made g).  Polled by the first wave with scalar loads, the others wait at the workgroup barrier (fft_team.h).
-    auto wait_all = [&](int g) __attribute__((always_inline)) {
+    // learn: the poll that sees the arrivals also brings the word behind the counter -- the transform the team takes next (see `pub`
+    // below) -- and leaves it in sh[4] for the workgroup
+    auto wait_all = [&](int g, bool learn = false) __attribute__((always_inline)) {
         FFT_LDS_FRESH();
         if (sh[3]) return;
         if (tid < FFT_TEAM_POLL_LANES) {
             const long long tstart = FFT_CLOCK();
-            while ((int)(FFT_L2_COUNT_POLL(flags) - ((unsigned)g << LOG2TS)) < 0) {
+            for (;;) {
+                const unsigned long long both = FFT_L2_COUNT_POLL2(flags);
+                if ((int)((unsigned)both - ((unsigned)g << LOG2TS)) >= 0) {
+                    if (learn && tid == 0) sh[4] = (unsigned)(both >> 32);
+                    break;
+                }
                 if (FFT_CLOCK() - tstart > p.timeout_ticks) {
                     team_report_timeout(p);
                     sh[3] = 1;
@@ -302,8 +314,13 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
         return (x & (L2 / 2)) ? hi : lo;
     };
 
-    auto in_of = [&](int it) __attribute__((always_inline)) { return p.in + (long long)(team + (long long)it * n_teams) * n; };
-    auto out_of = [&](int it) __attribute__((always_inline)) { return p.out + (long long)(team + (long long)it * n_teams) * n; };
+    // Which transform a team takes next: team + it * n_teams (static), or -- p.dynamic -- the next one nobody has claimed: the teams of
+    // different XCDs run 2 - 4 % apart (profiles/r3_quad_teams.txt), and a static split ends with seven XCDs waiting for the eighth.  The
+    // first seat claims transform it + 1 from a device-wide counter during transform it and stores it in the word behind the team's arrival
+    // counter before its arrival of round 1; the team wait of round 2 -- which waits for a later arrival -- reads counter and word in one
+    // access (wait_all(.., learn)), the workgroup finds it in LDS in round 3 (value = index + 1).
+    unsigned* const claim = p.ctl + TEAM_CTL_NEXT;
+    unsigned* const pub = flags + 1;
 
     // LDS-DMA of column chunk a (rows 4 b + a of my NC columns) into image `im`: lane-linear 16-byte pieces, piece
     // i NTHR + tid is image row (i NTHR + tid) / PPR, columns 2 ((i NTHR + tid) mod PPR) ..
@@ -345,11 +362,25 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
         ck[k] = mk<T>(pw4 == 0 ? p.scale : pw4 == 2 ? -p.scale : (T)0, pw4 == 1 ? p.scale : pw4 == 3 ? -p.scale : (T)0);
     }
 
-    dma_chunk(in_of(0), 0, 0);
-    for (int it = 0; it < NTR; it++) {
-        const cpx<T>* inb = in_of(it);
-        cpx<T>* outb = out_of(it);
+    long long cur = team;  // the transform in hand
+    dma_chunk(p.in + cur * n, 0, 0);
+    for (int it = 0; cur < p.nb; it++) {
+        FFT_LDS_FRESH();
+        if (sh[3]) break;  // a team wait has timed out: the launch is void (team_report_timeout), stop here
+        const cpx<T>* inb = p.in + cur * n;
+        cpx<T>* outb = p.out + cur * n;
         const int G = (QUAD_ONE_SLOT ? 8 : 5) * it;  // arrivals made before this transform
+        unsigned claimed = 0;
+        long long nxt = p.nb;
+        auto learn_next = [&]() __attribute__((always_inline)) {
+            if (p.dynamic) {
+                FFT_LDS_FRESH();
+                const unsigned v = FFT_UNIFORM(sh[4]);
+                nxt = v ? (long long)v - 1 : (long long)p.nb;
+            } else {
+                nxt = cur + n_teams;
+            }
+        };
 
         // ================= column step: four chunks, length-M transforms, results x W_L^(a kb) kept
         cpx<T> blk[4][E];
@@ -362,6 +393,10 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
             else FFT_WAIT_VM0();
             FFT_SYNC_LDS();
             ev();
+            // the claim for the transform after this one (used at the combine: its latency is hidden).  Issued HERE, behind the wait that
+            // counts the previous transform's result stores (vmcnt counts in issue order: in front of it the claim would make its wave
+            // wait for the first of those stores, and the team for that wave: -10 % at n = 2^20)
+            if (a == 3 && p.dynamic && s == 0 && tid == 0) claimed = FFT_ATOMIC_ADD_AGENT_RELAXED(claim, 1u) + (unsigned)n_teams;
             if (a + 1 < 4) dma_chunk(inb, a + 1, (a + 1) & 1);
             cpx<T>* img = reinterpret_cast<cpx<T>*>(img_b[a & 1]);
             int t = tid0;
@@ -499,13 +534,17 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
         // image of round r + 1 is requested at the stage barrier and flies under the second stage.
         FFT_UNROLL
         for (int r = 0; r < 4; r++) {
+            if (r == 1 && p.dynamic && s == 0 && tid == 0) FFT_L2_FLAG_STORE(pub, claimed + 1u);
             FFT_WAIT_VM0();  // the round's image has landed ...
             FFT_SYNC_LDS();  // ... everybody's of this workgroup
             arrive();  // L_r
             ev();
-            if (r == 3 && it + 1 < NTR) dma_chunk(in_of(it + 1), 0, 0);  // image 0 was last read in round 2
+            if (r == 3) {
+                learn_next();
+                if (nxt < p.nb) dma_chunk(p.in + nxt * n, 0, 0);  // image 0 was last read in round 2
+            }
             if (r < 3) {
-                wait_all(G + 2 * r + 2);  // the team's
+                wait_all(G + 2 * r + 2, r == 2);  // the team's
                 send(r + 1);
             }
             cpx<T>* img = reinterpret_cast<cpx<T>*>(img_b[r & 1]);
@@ -535,11 +574,15 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
         } else {
         FFT_UNROLL
         for (int r = 0; r < 4; r++) {
+            if (r == 1 && p.dynamic && s == 0 && tid == 0) FFT_L2_FLAG_STORE(pub, claimed + 1u);
             FFT_WAIT_VM0();  // the round's image has landed and my round-(r + 1) values are in L2 ...
             FFT_SYNC_LDS();  // ... everybody's
             arrive();  // arrival G + r + 2 (r = 3: G + 5, "my image of round 3 has landed")
             ev();
-            if (r == 3 && it + 1 < NTR) dma_chunk(in_of(it + 1), 0, 0);  // image 0 was last read in round 2
+            if (r == 3) {
+                learn_next();
+                if (nxt < p.nb) dma_chunk(p.in + nxt * n, 0, 0);  // image 0 was last read in round 2
+            }
             cpx<T>* img = reinterpret_cast<cpx<T>*>(img_b[r & 1]);
             int t = tid0;
             FFT_OPAQUE(t);
@@ -553,7 +596,7 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
                 // the next round's image is requested NOW (the other image was last read in round r - 1) and flies under this
                 // round's second stage; behind it the values of round r + 2, into the slot this round's image came from
                 // (everybody's image of round r has landed: arrival G + r + 2 says so)
-                wait_all(G + r + 2);
+                wait_all(G + r + 2, r == 2);
                 ev();
                 dma_window((r + 1) & 1, (r + 1) & 1);
                 if (r < 2) send(r + 2);
@@ -603,6 +646,7 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
             }
         }
         ev();
+        cur = nxt;
     }
 }
 

@@ -229,6 +229,23 @@ def test_team_quad_kernel(n, batch, log2seats, n_xcc, threads, lds, monkeypatch)
             assert rel(y, oracle(x, d)) < TEAM_TOL[np.complex64], (n, batch, d, inplace)
 
 
+def test_team_quad_kernel_static_and_dynamic_split_of_the_batch(monkeypatch):
+    """team_quad_kernel takes its transforms either by the static rule team + it * n_teams or -- the default -- by claiming the next
+    unclaimed one from a device-wide counter (the first seat claims, the team learns the index through its L2 line).  Both give the
+    same spectra, bit for bit; ragged batches, more teams than transforms, one team per "XCD" and two."""
+    monkeypatch.setenv("FFT_EMU_TEAM_QUAD", "1")
+    for n, batch, log2seats, n_xcc, threads, lds in ((4096, 11, 2, 3, 64, 8192), (2048, 9, 2, 2, 32, 4096), (1024, 3, 2, 2, 16, 2048), (1024, 13, 2, 1, 32, 4096)):
+        x = O.gen_lcg(n, 29, batch).astype(np.complex64)
+        res = []
+        for dyn in ("0", "1"):
+            monkeypatch.setenv("FFT_HIP_TEAM_DYNAMIC", dyn)
+            y, info = E.emu_fft_team(x, -1, log2seats=log2seats, n_xcc=n_xcc, threads=threads, lds_budget=lds)
+            assert info[6] & 8 and info[5] == 1, (n, dyn, info[5])
+            assert rel(y, oracle(x, -1)) < TEAM_TOL[np.complex64], (n, batch, dyn)
+            res.append(y)
+        assert np.array_equal(res[0], res[1])
+
+
 @pytest.mark.parametrize("quad", [False, True])
 def test_team_kernel_timeout_is_repaired_on_the_multi_pass_schedule(quad, monkeypatch):
     """VERDICT r2 item 6.  A member of a formed team never arrives (FFT_EMU_DROP_BLOCK leaves right after formation): the team's

@@ -50,7 +50,7 @@ def main():
             prev = t[:, base + i]
 
 
-if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] == "seats"):
+if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] in ("seats", "teams")):
     main()
 
 
@@ -97,3 +97,40 @@ def per_seat():
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "seats":
     per_seat()
+
+
+def per_team():
+    """python tools/quad_trace.py teams: when each team finishes its share of the batch (n = 2^20 x 512: 64 transforms per team)"""
+    n = 1 << 20
+    batch = 512
+    fftlib.init()
+    x = O.gen_lcg(n, 3, 8).astype(np.complex64)
+    x = np.tile(x, (batch // 8, 1))
+    buf, out = fftlib.DeviceBuffer(x.nbytes), fftlib.DeviceBuffer(x.nbytes)
+    buf.upload(x)
+    plan = fftlib.Plan(n, batch, -1, np.complex64)
+    NTR = batch // 8
+    events = 1 + 16 * NTR + 1
+    tr = fftlib.DeviceBuffer(256 * events * 8)
+    tr.upload(np.zeros(256 * events, dtype=np.int64))
+    plan.timed(buf.ptr, out.ptr, 3)
+    plan.lib.fft_gpu_plan_team_trace_hip(plan.handle, tr.ptr, events)
+    for rep in range(3):
+        plan.execute_ptr(buf.ptr, out.ptr)
+        plan.team_status()
+        raw = tr.download((256, events), np.int64)
+        t = raw.astype(np.float64) / 100.0
+        team = raw[:, events - 1] >> 8
+        t0 = t[:, 0].min()
+        print("run %d: team: formed at us | first transform done | finished at | us per transform (steady)" % rep)
+        ends = []
+        for tm in range(8):
+            rows = t[team == tm]
+            done = rows[:, 1 + 16 * np.arange(NTR) + 15].max(axis=0)  # stores issued, slowest seat, per transform
+            ends.append(done[-1] - t0)
+            print("  %d: %7.2f | %7.2f | %8.2f | %.2f" % (tm, rows[:, 0].max() - t0, done[0] - t0, done[-1] - t0, (done[-1] - done[3]) / (NTR - 4)))
+        print("  finish spread %.1f us of %.1f (%.1f %%)" % (max(ends) - min(ends), max(ends), 100 * (max(ends) - min(ends)) / max(ends)))
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "teams":
+    per_team()
