@@ -274,6 +274,10 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
     auto wait_all = [&](int g, bool learn = false) __attribute__((always_inline)) {
         FFT_LDS_FRESH();
         if (sh[3]) return;
+        if (FFT_ABLATE(p.ablate & 8)) {  // profiling only (experiments build): no poll -- what the team waits cost (results invalid)
+            FFT_SYNC_LDS();
+            return;
+        }
         if (tid < FFT_TEAM_POLL_LANES) {
             const long long tstart = FFT_CLOCK();
             for (;;) {
