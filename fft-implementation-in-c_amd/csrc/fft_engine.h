@@ -292,7 +292,7 @@ class Pow2Plan {
     // radix-E and a radix-RA / RB stage), teams of TS = L2 RA / threads seats.  Device (512 threads, E = 16): n = 2^20 (RA RB 16 16,
     // teams of 32), 2^19 (16 8, 16), 2^18 (8 8, 8), 2^17 (8 4, 4), 2^16 (4 4, 2); emulation (E = 4): n = 2^12 (4 4), 2^11 (4 2)
     // and 2^10 (2 2).  Tables [W_n^x, x < L2/2 | W_L1^y, y < L1 | W_L2^y, y < L2 | W_n^(L2/2)]; window: 2 slots of TS images per team.
-    static constexpr int quad_E(int log2n_) { return (log2n_ >= 16 && log2n_ <= 20) ? 16 : (log2n_ >= 10 && log2n_ <= 12) ? 4 : 0; }
+    static constexpr int quad_E(int log2n_) { return (log2n_ >= 15 && log2n_ <= 20) ? 16 : (log2n_ >= 10 && log2n_ <= 12) ? 4 : 0; }
     void build_team_quad(int batch) {
         const int mode = rt->policy.team_mode;
         if (mode <= 0 || SZ != 8) return;
@@ -306,13 +306,13 @@ class Pow2Plan {
         if (RB < 2 || RA > E || RA * E * 4 != L1 || RB * E * 4 != L2) return;
         const int log2TE = log2L1 - 2 + ilog2(d.nthreads) - ilog2(RA);  // values of a chunk image: MA rows x (threads / RA) columns
         d.log2TS = log2n - 2 - log2TE;
-        if (d.log2TS < 1 || d.log2TS > d.log2seats) return;
+        if (d.log2TS < 0 || d.log2TS > d.log2seats) return;
         const long long NC = L2 >> d.log2TS, NR = L1 >> d.log2TS;
-        if (NC * RA != d.nthreads || NR * RB != d.nthreads || NC < 8 || NR > 2 * (L1 / 4)) return;
+        if (NC * RA != d.nthreads || NR * RB != d.nthreads || NC < 8) return;
 #if !defined(FFT_EMU)
-        if (d.log2TS != (log2n == 20 ? 5 : log2n == 19 ? 4 : log2n == 18 ? 3 : log2n == 17 ? 2 : 1)) return;  // the device instantiations
+        if (d.log2TS != log2n - 15) return;  // the device instantiations
 #else
-        if (!((log2n == 12 && d.log2TS == 2) || ((log2n == 11 || log2n == 10) && (d.log2TS == 1 || d.log2TS == 2)))) return;  // the emulation's
+        if (!((log2n == 12 && d.log2TS == 2) || ((log2n == 11 || log2n == 10) && (d.log2TS == 1 || d.log2TS == 2)) || (log2n == 10 && d.log2TS == 0))) return;  // the emulation's
 #endif
         if (mode == 1 && !rt->team_default_on(SZ, log2n)) return;
         d.quad = true;
@@ -346,12 +346,12 @@ class Pow2Plan {
         }
         rt->memset_async(d.sticky, 0, fftk::TEAM_STICKY_WORDS * sizeof(unsigned));
         rt->h2d(d.tables, blob.data(), blob.size() * SZ);
-        // batch crossover against the multi-pass schedule (tools/batch_crossover.py; profiles/r3_batch_crossover.txt):
-        // n = 2^20 from 128 MiB per execute (117 vs 112 Gpoint/s at 16 transforms), 2^19 from 256 MiB (155 vs 133), 2^18 from 512 MiB
-        // (192 vs 169), 2^17 from 512 MiB (196 vs 177), 2^16 from 1 GiB (207 vs 185); and at least 4 transforms per team
+        // batch crossover against the multi-pass schedule (tools/batch_crossover.py; profiles/r3_batch_crossover.txt, the last table --
+        // measured after team formation had shrunk from 40 to 15 us): n = 2^20 and 2^19 from 128 MiB per execute (145 vs 111, 151 vs 123
+        // Gpoint/s), 2^18 ... 2^15 from 256 MiB (178 vs 164, 189 vs 169, 188 vs 174, 188 vs 179); and at least 2 transforms per team
         {
-            const long long mib = d.log2TS >= 5 ? 128 : d.log2TS == 4 ? 256 : d.log2TS >= 2 ? 512 : 1024;
-            d.min_batch = mode == 1 ? (int)std::max<long long>(4ll * d.n_teams, (mib << 20) / ((long long)SZ << log2n)) : d.n_teams;
+            const long long mib = d.log2TS >= 4 ? 128 : 256;
+            d.min_batch = mode == 1 ? (int)std::max<long long>(2ll * d.n_teams, (mib << 20) / ((long long)SZ << log2n)) : d.n_teams;
         }
         if (rt->policy.team_min_batch > 0) d.min_batch = rt->policy.team_min_batch;
         (void)batch;
@@ -367,6 +367,7 @@ class Pow2Plan {
             if (log2n == 12) FFT_QUAD_GO(4, 2, 2, 6, 6, 2, 2);
             else if (log2n == 11 && team.log2TS == 1) FFT_QUAD_GO(4, 2, 1, 6, 5, 1, 2);
             else if (log2n == 11) FFT_QUAD_GO(4, 2, 1, 6, 5, 2, 1);
+            else if (team.log2TS == 0) FFT_QUAD_GO(4, 1, 1, 5, 5, 0, 1);
             else if (team.log2TS == 1) FFT_QUAD_GO(4, 1, 1, 5, 5, 1, 1);
             else FFT_QUAD_GO(4, 1, 1, 5, 5, 2, 1);
 #else
@@ -377,6 +378,7 @@ class Pow2Plan {
             else if (log2n == 19) FFT_QUAD_GO(16, 4, 3, 10, 9, 4, 2);
             else if (log2n == 18) FFT_QUAD_GO(16, 3, 3, 9, 9, 3, 1);
             else if (log2n == 17) FFT_QUAD_GO(16, 3, 2, 9, 8, 2, 1);
+            else if (log2n == 15) FFT_QUAD_GO(16, 2, 1, 8, 7, 0, 1);
             else FFT_QUAD_GO(16, 2, 2, 8, 8, 1, 1);
 #endif
 #undef FFT_QUAD_GO

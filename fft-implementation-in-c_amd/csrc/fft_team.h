@@ -150,9 +150,16 @@ FFT_DEVICE void team_form(const TeamParams<T>& p, unsigned* sh) {
         // exactly n_xcc XCC ids must hold a full set of seats and no other id any workgroup.  WHICH ids is the hardware's
         // business: a partition of the device (DPX / QPX / CPX) need not number its XCDs from 0, so a team is
         // numbered by the RANK of its XCC id among the ids present, not by the id itself.
+        // (sixteen RELAXED device-scope loads, all in flight at once: the acquire load of REGISTERED above has ordered them behind every
+        // registration, and sixteen acquire loads in a row -- a memory round trip and a cache invalidate each -- made formation 40 us
+        // of every launch, profiles/r3_quad_fill.txt)
+        unsigned cnts[16];
+        FFT_UNROLL
+        for (int x = 0; x < 16; x++) cnts[x] = FFT_L2_FLAG_LOAD(&p.ctl[TEAM_CTL_COUNT + 32 * x]);
         int full = 0;
+        FFT_UNROLL
         for (int x = 0; x < 16; x++) {
-            const unsigned cnt = FFT_ATOMIC_LOAD_AGENT(&p.ctl[TEAM_CTL_COUNT + 32 * x]);
+            const unsigned cnt = cnts[x];
             if (cnt == (1u << p.log2seats)) {
                 full++;
                 if ((unsigned)x < xcc) xcc_rank++;

@@ -28,7 +28,8 @@
 // them in the exchange and never waited for on the spot; HBM traffic per transform: n in, n out.
 //
 // Shapes (fft_team_quad_decl.h): n = 2^20 = 1024 x 1024 (RA = RB = 16, teams of 32), 2^19 = 1024 x 512 (16, 8; teams of 16),
-// 2^18 = 512 x 512 (8, 8; 8), 2^17 = 512 x 256 (8, 4; 4), 2^16 = 256 x 256 (4, 4; 2); the emulation runs E = 4 with
+// 2^18 = 512 x 512 (8, 8; 8), 2^17 = 512 x 256 (8, 4; 4), 2^16 = 256 x 256 (4, 4; 2), 2^15 = 256 x 128 (4, 2; a "team" of ONE: the
+// transform's 256 KiB live in one CU's registers, the exchange is the CU's own 64 KiB of L2); the emulation runs E = 4 with
 // 64 x 64, 64 x 32 and 32 x 32.
 #pragma once
 
@@ -74,7 +75,8 @@ struct QuadShape {
     static constexpr int ILN = (64 / RA < NC / 4) ? 64 / RA : NC / 4;  // columns of a class per sender group (a wave on the device)
     static_assert(L1 == 4 * MA && L2 == 4 * MB && RA <= E && RA >= 2 && RB <= E && RB >= 2, "L = 4 M, M = E R: a radix-E and a radix-R stage");
     static_assert(NC * RA == NR * RB, "both steps use every thread");
-    static_assert(NC >= 8 && TS >= 2 && NR <= 2 * MA, "four classes of at least two columns; a seat's rows span at most two row blocks");
+    // the block of MA rows a row of the row step lies in must be the same for a whole wave (a group of 64 threads along the rows)
+    static_assert(NC >= 8 && TS >= 1 && (NR <= 2 * MA || MA % 64 == 0 || E == 4), "four classes of at least two columns; row blocks of whole waves");
 };
 
 // rotation of the column step's exchange image: the value of (row R, column c) sits at position (c + quad_phi(R / E)) mod NC
@@ -223,6 +225,7 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
     constexpr long long n = (long long)L1 * L2;
     static_assert(NTHR * NCH * 16 == (int)IMG && NTHR % PPR == 0, "a chunk image is NCH pieces per thread");
     FFT_DYN_SMEM(smem);
+    const long long t_entry = p.trace ? FFT_CLOCK() : 0;  // (tools/quad_trace.py teams: what formation costs)
 
     const int tid0 = FFT_TID;
     const int tid = tid0;
@@ -266,6 +269,7 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
     };
     ev();
     if (p.trace && tid == 0 && p.trace_events > 1) p.trace[(long long)FFT_BID * p.trace_events + p.trace_events - 1] = (team << 8) | s;
+    if (p.trace && tid == 0 && p.trace_events > 2) p.trace[(long long)FFT_BID * p.trace_events + p.trace_events - 2] = t_entry;
 
     // everybody has made arrival number g <=> the team's counter >= TS * g (nobody makes arrival g + 1 before everybody has
     // made g).  Polled by the first wave with scalar loads, the others wait at the workgroup barrier (fft_team.h).

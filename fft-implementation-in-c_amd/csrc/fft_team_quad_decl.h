@@ -25,7 +25,8 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
     X(float, 16, 4, 3, 10, 9, 4, 1)                                                                                    \
     X(float, 16, 3, 3, 9, 9, 3, 1)   /* n = 2^18: 512 x 512, teams of 8, one window slot */                            \
     X(float, 16, 3, 2, 9, 8, 2, 1)   /* n = 2^17: 512 x 256, teams of 4 */                                             \
-    X(float, 16, 2, 2, 8, 8, 1, 1)   /* n = 2^16: 256 x 256, teams of 2 */
+    X(float, 16, 2, 2, 8, 8, 1, 1)   /* n = 2^16: 256 x 256, teams of 2 */                                             \
+    X(float, 16, 2, 1, 8, 7, 0, 1)   /* n = 2^15: 256 x 128, one CU per transform */
 #define FFT_QUAD_EXTERN(T, ...) extern template __global__ void team_quad_kernel<T, __VA_ARGS__>(TeamParams<T>);
 FFT_QUAD_INSTANCES(FFT_QUAD_EXTERN)
 #undef FFT_QUAD_EXTERN

@@ -209,6 +209,7 @@ QUAD_CASES = [  # n, batch, log2seats, "XCDs", threads, LDS bytes
     (2048, 5, 1, 2, 64, 8192),    # n = 64 x 32 (the device's 2^19 = 1024 x 512 and 2^17 = 512 x 256): column step 4 x 4, row step 4 x 2; teams of 2, two window slots
     (2048, 7, 2, 2, 32, 4096),    # ... teams of 4 (NC = 8 columns, NR = 16 rows per seat), one window slot
     (2048, 6, 2, 1, 64, 8192),    # two teams of 2 on one "XCD"
+    (1024, 9, 2, 2, 64, 8192),    # a "team" of ONE (the device's n = 2^15 = 256 x 128): the seat's rows span all four row blocks
 ]
 
 

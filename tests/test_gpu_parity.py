@@ -510,11 +510,11 @@ def _team_plan(monkeypatch, n, batch, direction, dtype, mode="2"):
     return plan
 
 
-@pytest.mark.parametrize("log2n,dtype", [(20, np.complex64), (19, np.complex64), (18, np.complex64), (17, np.complex64),
+@pytest.mark.parametrize("log2n,dtype", [(20, np.complex64), (19, np.complex64), (18, np.complex64), (17, np.complex64), (15, np.complex64),
                                          (16, np.complex64), (19, np.complex128), (18, np.complex128),
                                          (17, np.complex128), (16, np.complex128), (15, np.complex128)])
 def test_team_kernel_vs_oracle(gpu_lib, monkeypatch, log2n, dtype):
-    """All ten device instantiations: teams of 32 (a whole XCD), 16, 8, 4 and 2 CUs."""
+    """Every device instantiation: teams of 32 (a whole XCD), 16, 8, 4 and 2 CUs -- and of one (n = 2^15 fp32, team_quad_kernel)."""
     import fftlib
     tiles = 4
     n = 1 << log2n
@@ -556,14 +556,14 @@ def test_team_kernel_vs_oracle(gpu_lib, monkeypatch, log2n, dtype):
 
 def test_team_kernel_default_policy_and_full_size(gpu_lib, monkeypatch):
     """BASELINE configs[2] as bench.py runs it: N = 2^20 fp32 x 512 takes the team kernel by default; every one of
-    the 512 spectra is checked against the analytic two-tone answer; a batch of 16 (below the measured crossover of 32
-    transforms, profiles/r2_batch_crossover.txt) keeps the two-pass schedule."""
+    the 512 spectra is checked against the analytic two-tone answer; a batch of 8 (below the measured crossover of 16
+    transforms, profiles/r3_batch_crossover.txt) keeps the two-pass schedule."""
     import fftlib
     fftlib.set_policy(team=1, min_batch=0)
     n, batch = 1 << 20, 512
-    small = fftlib.Plan(n, 16, -1, np.complex64)
+    small = fftlib.Plan(n, 8, -1, np.complex64)
     assert small.info().team_tiles == 4  # planned ...
-    xs = lcg(n, 16, np.complex64, seed=5)
+    xs = lcg(n, 8, np.complex64, seed=5)
     bs = fftlib.DeviceBuffer(xs.nbytes)
     bs.upload(xs)
     small.execute_ptr(bs.ptr, bs.ptr)

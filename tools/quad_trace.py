@@ -100,36 +100,39 @@ if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "seats":
 
 
 def per_team():
-    """python tools/quad_trace.py teams: when each team finishes its share of the batch (n = 2^20 x 512: 64 transforms per team)"""
-    n = 1 << 20
-    batch = 512
+    """python tools/quad_trace.py teams [log2n batch]: kernel entry, team formation, first transform and the end of every team's share
+    of the batch (ev() slots per transform: 16; the slot before the identity word holds the workgroup's entry time)"""
+    log2n = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+    batch = int(sys.argv[3]) if len(sys.argv) > 3 else 512
+    n = 1 << log2n
     fftlib.init()
     x = O.gen_lcg(n, 3, 8).astype(np.complex64)
     x = np.tile(x, (batch // 8, 1))
     buf, out = fftlib.DeviceBuffer(x.nbytes), fftlib.DeviceBuffer(x.nbytes)
     buf.upload(x)
     plan = fftlib.Plan(n, batch, -1, np.complex64)
-    NTR = batch // 8
-    events = 1 + 16 * NTR + 1
+    n_teams = 8 << (20 - log2n)
+    NTR = 2 * batch // n_teams + 2  # (claimed transforms: a team may take more than its even share)
+    events = 1 + 16 * NTR + 2
     tr = fftlib.DeviceBuffer(256 * events * 8)
-    tr.upload(np.zeros(256 * events, dtype=np.int64))
     plan.timed(buf.ptr, out.ptr, 3)
+    ms = plan.timed(buf.ptr, out.ptr, 10) / 10
+    print("n=2^%d batch %d: %.3f ms per execute = %.1f Gpoint/s" % (log2n, batch, ms, n * batch / ms / 1e6))
     plan.lib.fft_gpu_plan_team_trace_hip(plan.handle, tr.ptr, events)
     for rep in range(3):
+        tr.upload(np.zeros(256 * events, dtype=np.int64))
         plan.execute_ptr(buf.ptr, out.ptr)
         plan.team_status()
         raw = tr.download((256, events), np.int64)
         t = raw.astype(np.float64) / 100.0
-        team = raw[:, events - 1] >> 8
-        t0 = t[:, 0].min()
-        print("run %d: team: formed at us | first transform done | finished at | us per transform (steady)" % rep)
-        ends = []
-        for tm in range(8):
-            rows = t[team == tm]
-            done = rows[:, 1 + 16 * np.arange(NTR) + 15].max(axis=0)  # stores issued, slowest seat, per transform
-            ends.append(done[-1] - t0)
-            print("  %d: %7.2f | %7.2f | %8.2f | %.2f" % (tm, rows[:, 0].max() - t0, done[0] - t0, done[-1] - t0, (done[-1] - done[3]) / (NTR - 4)))
-        print("  finish spread %.1f us of %.1f (%.1f %%)" % (max(ends) - min(ends), max(ends), 100 * (max(ends) - min(ends)) / max(ends)))
+        entry = t[:, events - 2]
+        t0 = entry.min()
+        ev = t[:, :events - 2]
+        last = np.array([row[row > 0].max() if (row > 0).any() else 0.0 for row in ev])  # the workgroup's last event
+        first_done = ev[:, 16]                                    # stores of its first transform issued
+        cnt = np.array([(row[1:] > 0).sum() // 16 for row in ev])  # transforms it took part in
+        print("run %d: workgroups enter %.1f .. %.1f us, teams formed %.1f .. %.1f, first transform done %.1f .. %.1f, last event %.1f .. %.1f; transforms per workgroup %d .. %d" %
+              (rep, 0.0, entry.max() - t0, ev[:, 0].min() - t0, ev[:, 0].max() - t0, first_done.min() - t0, first_done.max() - t0, last.min() - t0, last.max() - t0, cnt.min(), cnt.max()))
 
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "teams":
