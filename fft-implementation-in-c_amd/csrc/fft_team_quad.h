@@ -258,6 +258,9 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
     if (FFT_TEST_DROP()) return;  // emulation only: a member that never arrives
 
     unsigned char* const sbase = p.scratch + (size_t)team * SLOTS * SLOT;
+    // profiling only (experiments build, results invalid): the second slot aliases half (bit 16) or all (bit 32) of the first -- the
+    // two-slot protocol on a window of 3 / 2 MiB per XCD instead of 4: what a smaller window would be worth
+    const size_t slot_stride = FFT_ABLATE(p.ablate & 32) ? 0 : FFT_ABLATE(p.ablate & 16) ? SLOT / 2 : SLOT;
     unsigned* const flags = p.ctl + TEAM_CTL_FLAGS + 32 * team;
 
     int n_ev = 0;
@@ -350,7 +353,7 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
     auto dma_window = [&](int slot, int im) __attribute__((always_inline)) {
         int tid = tid0;
         FFT_OPAQUE(tid);
-        const unsigned char* src = sbase + (size_t)slot * SLOT + (size_t)s * IMG + (size_t)tid * 16;
+        const unsigned char* src = sbase + (size_t)slot * slot_stride + (size_t)s * IMG + (size_t)tid * 16;
         const unsigned lds = img_lds0 + (unsigned)im * IMG;
         if (p.nt_mask & 4) {
             FFT_UNROLL
@@ -457,7 +460,7 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
             FFT_OPAQUE(t);
             const int g = t & (RA - 1);
             const int q = (r - ap) & 3;
-            unsigned char* const wslot = sbase + (size_t)(QUAD_ONE_SLOT ? 0 : (r & 1)) * SLOT;
+            unsigned char* const wslot = sbase + (size_t)(QUAD_ONE_SLOT ? 0 : (r & 1)) * slot_stride;
             const int bprime = (NC / 4) * s + sender_cc(t);  // (j2 - ap) / 4: my column's place in its class
             FFT_UNROLL
             for (int i = 0; i < E / 2; i++) {
