@@ -292,15 +292,21 @@ class Pow2Plan {
     // radix-E and a radix-RA / RB stage), teams of TS = L2 RA / threads seats.  Device (512 threads, E = 16): n = 2^20 (RA RB 16 16,
     // teams of 32), 2^19 (16 8, 16), 2^18 (8 8, 8), 2^17 (8 4, 4), 2^16 (4 4, 2); emulation (E = 4): n = 2^12 (4 4), 2^11 (4 2)
     // and 2^10 (2 2).  Tables [W_n^x, x < L2/2 | W_L1^y, y < L1 | W_L2^y, y < L2 | W_n^(L2/2)]; window: 2 slots of TS images per team.
-    static constexpr int quad_E(int log2n_) { return (log2n_ >= 15 && log2n_ <= 20) ? 16 : (log2n_ >= 10 && log2n_ <= 12) ? 4 : 0; }
+    // fp64 (one value per 16-byte access, 8 values per thread and chunk): n = 2^14 = 256 x 64 on one CU, 2^15 = 256 x 128 on teams of 2,
+    // 2^16 = 256 x 256 on teams of 4 (RA <= E: no larger size has two-stage sub-transforms).
+    static constexpr int quad_E(int log2n_) {
+        return SZ == 8 ? ((log2n_ >= 15 && log2n_ <= 20) ? 16 : (log2n_ >= 10 && log2n_ <= 12) ? 4 : 0)
+                       : ((log2n_ >= 14 && log2n_ <= 16) ? 8 : (log2n_ >= 10 && log2n_ <= 12) ? 4 : 0);
+    }
     void build_team_quad(int batch) {
         const int mode = rt->policy.team_mode;
-        if (mode <= 0 || SZ != 8) return;
+        if (mode <= 0) return;
         const int E = quad_E(log2n);
         if (!E || !rt->team_quad(SZ, log2n)) return;
         TeamDesc<T> d;
         if (!rt->team_geometry(d.log2seats, d.n_xcc, d.nthreads)) return;
-        const int log2L1 = (log2n + 1) / 2, log2L2 = log2n / 2;
+        // (fp64 2^14: 256 x 64, not 128 x 128 -- a wave of the row step must lie in ONE block of MA rows, and MA = 32 there)
+        const int log2L1 = (SZ == 16 && log2n == 14) ? 8 : (log2n + 1) / 2, log2L2 = log2n - log2L1;
         const long long L1 = 1ll << log2L1, L2 = 1ll << log2L2;
         const long long RA = L1 / 4 / E, RB = L2 / 4 / E;
         if (RB < 2 || RA > E || RA * E * 4 != L1 || RB * E * 4 != L2) return;
@@ -310,7 +316,7 @@ class Pow2Plan {
         const long long NC = L2 >> d.log2TS, NR = L1 >> d.log2TS;
         if (NC * RA != d.nthreads || NR * RB != d.nthreads || NC < 8) return;
 #if !defined(FFT_EMU)
-        if (d.log2TS != log2n - 15) return;  // the device instantiations
+        if (d.log2TS != log2n - (SZ == 8 ? 15 : 14)) return;  // the device instantiations
 #else
         if (!((log2n == 12 && d.log2TS == 2) || ((log2n == 11 || log2n == 10) && (d.log2TS == 1 || d.log2TS == 2)) || (log2n == 10 && d.log2TS == 0))) return;  // the emulation's
 #endif
@@ -361,28 +367,33 @@ class Pow2Plan {
 
     void launch_team_quad(const fftk::TeamParams<T>& tp) {
         const long long grid = (long long)team.n_xcc << team.log2seats;
-        if constexpr (SZ == 8) {
 #define FFT_QUAD_GO(...) rt->launch_coresident(fftk::team_quad_kernel<T, __VA_ARGS__>, grid, team.nthreads, (size_t)team.smem_bytes, tp)
 #if defined(FFT_EMU)
-            if (log2n == 12) FFT_QUAD_GO(4, 2, 2, 6, 6, 2, 2);
-            else if (log2n == 11 && team.log2TS == 1) FFT_QUAD_GO(4, 2, 1, 6, 5, 1, 2);
-            else if (log2n == 11) FFT_QUAD_GO(4, 2, 1, 6, 5, 2, 1);
-            else if (team.log2TS == 0) FFT_QUAD_GO(4, 1, 1, 5, 5, 0, 1);
-            else if (team.log2TS == 1) FFT_QUAD_GO(4, 1, 1, 5, 5, 1, 1);
-            else FFT_QUAD_GO(4, 1, 1, 5, 5, 2, 1);
+        if (log2n == 12) FFT_QUAD_GO(4, 2, 2, 6, 6, 2, 2);
+        else if (log2n == 11 && team.log2TS == 1) FFT_QUAD_GO(4, 2, 1, 6, 5, 1, 2);
+        else if (log2n == 11) FFT_QUAD_GO(4, 2, 1, 6, 5, 2, 1);
+        else if (team.log2TS == 0) FFT_QUAD_GO(4, 1, 1, 5, 5, 0, 1);
+        else if (team.log2TS == 1) FFT_QUAD_GO(4, 1, 1, 5, 5, 1, 1);
+        else FFT_QUAD_GO(4, 1, 1, 5, 5, 2, 1);
 #else
+        if constexpr (SZ == 8) {
             const int slots = rt->team_quad_slots(log2n);
             if (log2n == 20 && slots == 1) FFT_QUAD_GO(16, 4, 4, 10, 10, 5, 1);
             else if (log2n == 20) FFT_QUAD_GO(16, 4, 4, 10, 10, 5, 2);
             else if (log2n == 19 && slots == 1) FFT_QUAD_GO(16, 4, 3, 10, 9, 4, 1);
             else if (log2n == 19) FFT_QUAD_GO(16, 4, 3, 10, 9, 4, 2);
+            else if (log2n == 18 && slots == 2) FFT_QUAD_GO(16, 3, 3, 9, 9, 3, 2);
             else if (log2n == 18) FFT_QUAD_GO(16, 3, 3, 9, 9, 3, 1);
             else if (log2n == 17) FFT_QUAD_GO(16, 3, 2, 9, 8, 2, 1);
             else if (log2n == 15) FFT_QUAD_GO(16, 2, 1, 8, 7, 0, 1);
             else FFT_QUAD_GO(16, 2, 2, 8, 8, 1, 1);
+        } else {
+            if (log2n == 14) FFT_QUAD_GO(8, 3, 1, 8, 6, 0, 1);
+            else if (log2n == 15) FFT_QUAD_GO(8, 3, 2, 8, 7, 1, 1);
+            else FFT_QUAD_GO(8, 3, 3, 8, 8, 2, 1);
+        }
 #endif
 #undef FFT_QUAD_GO
-        }
         (void)grid;
     }
 

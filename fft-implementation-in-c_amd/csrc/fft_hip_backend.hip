@@ -137,7 +137,7 @@ struct HipRT {
     // sizes where the team kernel measured faster than the multi-pass schedule (tools/team_sweep.py at 4 GiB
     // per execute): fp32 2^16..2^20 (+14, +15, +24, +24, +15..19 %), fp64 2^15..2^19 (+28, +25, +35, +25, +16 %)
     bool team_default_on(int elem_bytes, int log2n) {
-        return elem_bytes == 8 ? (log2n >= 15 && log2n <= 20) : (log2n >= 15 && log2n <= 19);
+        return elem_bytes == 8 ? (log2n >= 15 && log2n <= 20) : (log2n >= 14 && log2n <= 19);
     }
     // the column step on 128-byte row segments (fft_team.h ASPLIT), instantiated for fp32 n = 2^20 where the plain
     // tiles have 64-byte ones.  Measured 125 vs 137 Gpoint/s (the joined halves concentrate twiddles and hand-over in
@@ -162,14 +162,14 @@ struct HipRT {
     // experiments build): 0 never, 1 every built size (default), or a bit mask: bit (log2n - 14) = that size only
     bool team_quad(int elem_bytes, int log2n) {
         static const int on = FFT_EXP_ENV("FFT_HIP_TEAM_QUAD") ? atoi(FFT_EXP_ENV("FFT_HIP_TEAM_QUAD")) : 1;
-        if (elem_bytes != 8 || log2n < 15 || log2n > 20) return false;
+        if (elem_bytes == 8 ? (log2n < 15 || log2n > 20) : (log2n < 14 || log2n > 16)) return false;
         if (on <= 1) return on == 1;
         return (on >> (log2n - 14)) & 1;
     }
     // window slots of team_quad_kernel where both protocols are built (n = 2^20, 2^19; the experiments build: FFT_HIP_QUAD_SLOTS=1 / 2)
     int team_quad_slots(int log2n) {
         static const int v = FFT_EXP_ENV("FFT_HIP_QUAD_SLOTS") ? atoi(FFT_EXP_ENV("FFT_HIP_QUAD_SLOTS")) : 0;
-        return v ? v : (log2n == 20 ? 2 : FFT_QUAD_SLOTS19);
+        return v ? v : (log2n == 20 ? 2 : log2n == 19 ? FFT_QUAD_SLOTS19 : 1);
     }
     // wide_row_kernel (fft_wide_row.h): single-pass n = 8192 and 16384 fp32.  FFT_HIP_WIDE=0 (the experiments build): the two-pass schedule
     bool wide_rows(int elem_bytes, int log2n) {

@@ -54,6 +54,19 @@
 #define QUAD_LD(p) (*(p))
 #define QUAD_ST(p, v) (*(p) = (v))
 #endif
+namespace fftk {
+// one value of the exchange image: 8 bytes (fp32: the single-form access above) or 16 (fp64: one ds_read_b128 / ds_write_b128)
+template <typename T>
+FFT_DEVICE cpx<T> quad_ld(const cpx<T>* p) {
+    if constexpr (sizeof(T) == 4) return QUAD_LD(p);
+    else return *p;
+}
+template <typename T>
+FFT_DEVICE void quad_st(cpx<T>* p, cpx<T> v) {
+    if constexpr (sizeof(T) == 4) QUAD_ST(p, v);
+    else *p = v;
+}
+}  // namespace fftk
 #ifndef QUAD_PAIR_DPP    // 1: the row-pair exchange in front of a 16-byte store as v_cndmask_b32_dpp (select and lane swap in one instruction)
 #define QUAD_PAIR_DPP 1
 #endif
@@ -71,7 +84,7 @@ struct QuadShape {
     static constexpr int L1 = 1 << LOG2L1, L2 = 1 << LOG2L2, TS = 1 << LOG2TS;
     static constexpr int LOG2NC = LOG2L2 - LOG2TS, NC = 1 << LOG2NC, LOG2NR = LOG2L1 - LOG2TS, NR = 1 << LOG2NR;
     static constexpr int NTHR = NC * RA;
-    static constexpr unsigned IMG = (unsigned)NC * MA * 8u;  // bytes of one chunk image (fp32) = NR MB 8
+    static constexpr unsigned IMG_VALUES = (unsigned)NC * MA;  // values of one chunk image = NR MB
     static constexpr int ILN = (64 / RA < NC / 4) ? 64 / RA : NC / 4;  // columns of a class per sender group (a wave on the device)
     static_assert(L1 == 4 * MA && L2 == 4 * MB && RA <= E && RA >= 2 && RB <= E && RB >= 2, "L = 4 M, M = E R: a radix-E and a radix-R stage");
     static_assert(NC * RA == NR * RB, "both steps use every thread");
@@ -147,7 +160,7 @@ FFT_DEVICE void quad_stage1(cpx<T>* img, const cpx<T>* wl, int col, int r, bool 
     static_assert(4 * (R2 - 1) * (E - 1) < (1 << LOG2L), "no wrap of the table index");
     cpx<T> x[E];
     FFT_UNROLL
-    for (int e = 0; e < E; e++) x[e] = QUAD_LD(&img[((r + R2 * e) << LOG2W) + col]);
+    for (int e = 0; e < E; e++) x[e] = quad_ld<T>(&img[((r + R2 * e) << LOG2W) + col]);
     cpx<T> pw[E];
     pw[1] = wl[4 * r];
     FFT_UNROLL
@@ -167,7 +180,7 @@ FFT_DEVICE void quad_stage1(cpx<T>* img, const cpx<T>* wl, int col, int r, bool 
     mark(0);
     if (ROT) FFT_WAVE_LOCKSTEP();  // the rotated positions were read by other lanes of this wave
     FFT_UNROLL
-    for (int k = 0; k < E; k++) QUAD_ST(&img[((r + R2 * k) << LOG2W) + (ROT ? quad_rot<R2, W>(col, k / G2) : col)], x[k]);
+    for (int k = 0; k < E; k++) quad_st<T>(&img[((r + R2 * k) << LOG2W) + (ROT ? quad_rot<R2, W>(col, k / G2) : col)], x[k]);
 }
 
 // Stage 2, the reads: thread g < R2 of column `col` takes the E values of rows E g + rr, i.e. for each of its G2 = E / R2
@@ -176,7 +189,7 @@ FFT_DEVICE void quad_stage1(cpx<T>* img, const cpx<T>* wl, int col, int r, bool 
 template <typename T, int E, int LOG2W>
 FFT_DEVICE void quad_stage2_read(cpx<T> (&v)[E], const cpx<T>* img, int pos, int g) {
     FFT_UNROLL
-    for (int rr = 0; rr < E; rr++) v[rr] = QUAD_LD(&img[((rr + E * g) << LOG2W) + pos]);
+    for (int rr = 0; rr < E; rr++) v[rr] = quad_ld<T>(&img[((rr + E * g) << LOG2W) + pos]);
 }
 // ... and the butterflies: v[i R2 + k] = Y[kb], kb = G2 g + i + E k  (quad_kb)
 template <typename T, int E, int R2>
@@ -211,16 +224,16 @@ template <typename T, int E, int LOG2RA, int LOG2RB, int LOG2L1, int LOG2L2, int
 FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamParams<T> p) {
     constexpr bool QUAD_ONE_SLOT = SLOTS == 1;
     static_assert(SLOTS == 1 || SLOTS == 2, "one or two window slots");
-    static_assert(vec16<T>::V == 2, "fp32: a 16-byte access holds the values of two adjacent rows");
+    constexpr int V = vec16<T>::V;  // values per 16-byte access: 2 (fp32: the values of two adjacent rows travel together), 1 (fp64)
     using S = QuadShape<E, LOG2RA, LOG2RB, LOG2L1, LOG2L2, LOG2TS>;
     constexpr int L1 = S::L1, L2 = S::L2, TS = S::TS, MA = S::MA, MB = S::MB, NC = S::NC, LOG2NC = S::LOG2NC, NR = S::NR, LOG2NR = S::LOG2NR;
     constexpr int NTHR = S::NTHR, RA = S::RA, RB = S::RB, GA = S::GA, ILN = S::ILN;
     constexpr int LOG2MA = LOG2L1 - 2;
     constexpr int LOG2ILN = Log2<ILN>::value;
-    constexpr int NCH = E / 2;   // 16-byte pieces of a chunk image per thread
-    constexpr int PPR = NC / 2;  // 16-byte pieces per image row
-    constexpr int SZ = 8;
-    constexpr unsigned IMG = S::IMG;
+    constexpr int NCH = E / V;   // 16-byte pieces of a chunk image per thread
+    constexpr int PPR = NC / V;  // 16-byte pieces per image row
+    constexpr int SZ = (int)sizeof(cpx<T>);
+    constexpr unsigned IMG = S::IMG_VALUES * (unsigned)SZ;  // bytes of one chunk image
     constexpr size_t SLOT = (size_t)TS * IMG;  // one window slot: every seat's image of one round
     constexpr long long n = (long long)L1 * L2;
     static_assert(NTHR * NCH * 16 == (int)IMG && NTHR % PPR == 0, "a chunk image is NCH pieces per thread");
@@ -338,7 +351,7 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
     auto dma_chunk = [&](const cpx<T>* inb, int a, int im) __attribute__((always_inline)) {
         int tid = tid0;
         FFT_OPAQUE(tid);
-        const cpx<T>* src = inb + ((long long)(4 * (tid / PPR) + a) << LOG2L2) + NC * s + 2 * (tid % PPR);
+        const cpx<T>* src = inb + ((long long)(4 * (tid / PPR) + a) << LOG2L2) + NC * s + V * (tid % PPR);
         constexpr long long step = (long long)(4 * (NTHR / PPR)) << LOG2L2;
         const unsigned lds = img_lds0 + (unsigned)im * IMG;
         if (p.nt_mask & 1) {
@@ -400,7 +413,7 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
             // my pieces of the chunk have landed ... everybody's have; the other image was last read before this barrier.
             // What may still be in flight behind chunk 0's DMA are the previous transform's 4 E / 2 result stores (vmcnt counts
             // in issue order)
-            if (it > 0 && a == 0) FFT_WAIT_VM_LE(2 * E);
+            if (it > 0 && a == 0) FFT_WAIT_VM_LE(4 * E / V);
             else FFT_WAIT_VM0();
             FFT_SYNC_LDS();
             ev();
@@ -462,6 +475,16 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
             const int q = (r - ap) & 3;
             unsigned char* const wslot = sbase + (size_t)(QUAD_ONE_SLOT ? 0 : (r & 1)) * slot_stride;
             const int bprime = (NC / 4) * s + sender_cc(t);  // (j2 - ap) / 4: my column's place in its class
+            if constexpr (V == 1) {  // fp64: one value per 16-byte store
+                FFT_UNROLL
+                for (int k = 0; k < E; k++) {
+                    const int k1 = quad_kb<E, RA>(g, k) + MA * q;
+                    const int dst_seat = k1 >> LOG2NR, rho = k1 & (NR - 1);
+                    vec16<T> v;
+                    v.c[0] = blk[r][k];
+                    *reinterpret_cast<vec16<T>*>(wslot + (size_t)dst_seat * IMG + (size_t)(((bprime << LOG2NR) + rho) * SZ)) = v;
+                }
+            } else {
             FFT_UNROLL
             for (int i = 0; i < E / 2; i++) {
                 vec16<T> v;
@@ -479,6 +502,7 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
                 }
                 const int dst_seat = k1 >> LOG2NR, rho = k1 & (NR - 1);
                 *reinterpret_cast<vec16<T>*>(wslot + (size_t)dst_seat * IMG + (size_t)(((bprime << LOG2NR) + rho) * SZ)) = v;
+            }
             }
         };
         // ---- combine: radix-4 over the chunks, then W_n^(k1 j2), k1 = kb + M q, q = (r - ap) mod 4 for block r
@@ -631,6 +655,25 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
             const int ncol = t & (NR - 1), nr = t >> LOG2NR;
             const bool odd = (ncol & 1) != 0;
             cpx<T>* const line0 = outb + NR * s + (ncol & ~1);
+            if constexpr (V == 1) {  // fp64: every value is a 16-byte store of its own, a wave instruction writes NR-row segments all the same
+                FFT_UNROLL
+                for (int i = 0; i < E; i++) {
+                    cpx<T> y[4];
+                    FFT_UNROLL
+                    for (int r = 0; r < 4; r++) y[r] = zt[r][i];
+                    dft_inplace<T, 4>(y);
+                    FFT_UNROLL
+                    for (int ka = 0; ka < 4; ka++) {
+                        vec16<T> v;
+                        v.c[0] = cmul(y[ka], ck[ka]);
+                        if (p.inverse) v.c[0] = cswap(v.c[0]);
+                        const long long k2 = quad_kb<E, RB>(nr, i) + MB * ka;
+                        vec16<T>* const dst = reinterpret_cast<vec16<T>*>(outb + NR * s + ncol + (k2 << LOG2L1));
+                        if (p.nt_mask & 2) FFT_STORE16_NT(dst, v);
+                        else *dst = v;
+                    }
+                }
+            } else {
             FFT_UNROLL
             for (int i = 0; i < E / 2; i++) {
                 cpx<T> y[2][4];
@@ -654,6 +697,7 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
                     if (p.nt_mask & 2) FFT_STORE16_NT(dst, v);
                     else *dst = v;
                 }
+            }
             }
         }
         ev();

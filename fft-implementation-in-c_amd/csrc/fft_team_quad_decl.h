@@ -24,9 +24,13 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
     X(float, 16, 4, 3, 10, 9, 4, 2)  /* n = 2^19: 1024 x 512, teams of 16 */                                           \
     X(float, 16, 4, 3, 10, 9, 4, 1)                                                                                    \
     X(float, 16, 3, 3, 9, 9, 3, 1)   /* n = 2^18: 512 x 512, teams of 8, one window slot */                            \
+    X(float, 16, 3, 3, 9, 9, 3, 2)   /* ... two (experiments) */                                                       \
     X(float, 16, 3, 2, 9, 8, 2, 1)   /* n = 2^17: 512 x 256, teams of 4 */                                             \
     X(float, 16, 2, 2, 8, 8, 1, 1)   /* n = 2^16: 256 x 256, teams of 2 */                                             \
-    X(float, 16, 2, 1, 8, 7, 0, 1)   /* n = 2^15: 256 x 128, one CU per transform */
+    X(float, 16, 2, 1, 8, 7, 0, 1)   /* n = 2^15: 256 x 128, one CU per transform */                                   \
+    X(double, 8, 3, 1, 8, 6, 0, 1)   /* fp64 n = 2^14: 256 x 64, one CU per transform */                               \
+    X(double, 8, 3, 2, 8, 7, 1, 1)   /* fp64 n = 2^15: 256 x 128, teams of 2 */                                        \
+    X(double, 8, 3, 3, 8, 8, 2, 1)   /* fp64 n = 2^16: 256 x 256, teams of 4 */
 #define FFT_QUAD_EXTERN(T, ...) extern template __global__ void team_quad_kernel<T, __VA_ARGS__>(TeamParams<T>);
 FFT_QUAD_INSTANCES(FFT_QUAD_EXTERN)
 #undef FFT_QUAD_EXTERN

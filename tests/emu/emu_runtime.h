@@ -50,7 +50,7 @@ struct Runtime {
     bool team_default_on(int, int) { return true; }
     bool team_defer(int, int) { return getenv("FFT_EMU_TEAM_PLAIN") == nullptr; }  // the shipped default; FFT_EMU_TEAM_PLAIN: team_fft_kernel
     bool team_asplit(int, int) { return getenv("FFT_EMU_TEAM_ASPLIT") != nullptr; }
-    bool team_quad(int elem_bytes, int log2n) { return elem_bytes == 8 && (log2n >= 10 && log2n <= 12) && getenv("FFT_EMU_TEAM_QUAD") != nullptr; }
+    bool team_quad(int, int log2n) { return (log2n >= 10 && log2n <= 12) && getenv("FFT_EMU_TEAM_QUAD") != nullptr; }
     bool wide_rows(int elem_bytes, int log2n) { return elem_bytes == 8 && log2n == 9 && getenv("FFT_EMU_WIDE") != nullptr; }
     bool team_alll2(int, int) { return getenv("FFT_EMU_TEAM_ALLL2") != nullptr; }
     bool team_nodefer(int, int) { return getenv("FFT_EMU_TEAM_NODEFER") != nullptr; }

@@ -213,21 +213,24 @@ QUAD_CASES = [  # n, batch, log2seats, "XCDs", threads, LDS bytes
 ]
 
 
+@pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
 @pytest.mark.parametrize("n,batch,log2seats,n_xcc,threads,lds", QUAD_CASES)
-def test_team_quad_kernel(n, batch, log2seats, n_xcc, threads, lds, monkeypatch):
+def test_team_quad_kernel(n, batch, log2seats, n_xcc, threads, lds, dtype, monkeypatch):
     """team_quad_kernel (fft_team_quad.h) in its emulated shapes: E = 4 values per thread and chunk, the length-L/4 transforms as
     4 x 4 (the device's n = 2^20 is 16 x 16) and as 4 x 2 (the device's 16 x 8 at 2^18 and 16 x 4 at 2^16: several radix-R2
     butterflies per thread in stage 2, adjacent rows in ONE thread at the hand-over), teams of 4 and of 2 seats, ragged batches,
     both directions, in place and out of place.  The device shapes are the same source with other constants;
     tests/test_gpu_parity.py covers them."""
     monkeypatch.setenv("FFT_EMU_TEAM_QUAD", "1")
-    x = O.gen_lcg(n, 23, batch).astype(np.complex64)
+    x = O.gen_lcg(n, 23, batch).astype(dtype)
+    if dtype == np.complex128:
+        lds *= 2  # (fp64: one value per 16-byte access -- the same shapes with images twice the bytes; the device's n = 2^14 ... 2^16)
     for d in (-1, 1):
         for inplace in (False, True):
             y, info = E.emu_fft_team(x, d, log2seats=log2seats, n_xcc=n_xcc, threads=threads, lds_budget=lds, inplace=inplace)
             assert info[0] // 100 == 4 and info[6] & 8, "team_quad_kernel was not planned"
             assert info[5] == 1, "status / fallback / timeout counters: %d" % info[5]
-            assert rel(y, oracle(x, d)) < TEAM_TOL[np.complex64], (n, batch, d, inplace)
+            assert rel(y, oracle(x, d)) < TEAM_TOL[dtype], (n, batch, d, inplace)
 
 
 def test_team_quad_kernel_static_and_dynamic_split_of_the_batch(monkeypatch):

@@ -512,7 +512,7 @@ def _team_plan(monkeypatch, n, batch, direction, dtype, mode="2"):
 
 @pytest.mark.parametrize("log2n,dtype", [(20, np.complex64), (19, np.complex64), (18, np.complex64), (17, np.complex64), (15, np.complex64),
                                          (16, np.complex64), (19, np.complex128), (18, np.complex128),
-                                         (17, np.complex128), (16, np.complex128), (15, np.complex128)])
+                                         (17, np.complex128), (16, np.complex128), (15, np.complex128), (14, np.complex128)])
 def test_team_kernel_vs_oracle(gpu_lib, monkeypatch, log2n, dtype):
     """Every device instantiation: teams of 32 (a whole XCD), 16, 8, 4 and 2 CUs -- and of one (n = 2^15 fp32, team_quad_kernel)."""
     import fftlib
