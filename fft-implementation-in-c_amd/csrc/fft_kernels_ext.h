@@ -42,38 +42,55 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS(256) transpose_kernel(const cpx<T>* in, cpx<T>
 //   O[k] = (Z[k] - conj(Z[h-k])) / (2i)       spectrum of the odd samples        (Z[h] = Z[0])
 //   X[k] = E[k] + W_n^k O[k],  k = 0 .. h      the n/2 + 1 non-redundant bins (reference include/fft_auto.h:88-96)
 // w[k] = W_n^k = exp(-2 pi i k / n), k <= h, comes from a plan-time table.  z: [batch][h], x_out: [batch][h + 1].
+// One thread per PAIR of bins (k, h - k), k = 0 .. h/2 (round 3: one thread per bin read every Z twice): with t = W_n^k O[k],
+//   X[k] = E[k] + t,   X[h-k] = conj(E[k] - t)      (E[h-k] = conj E[k], O[h-k] = conj O[k], W_n^(h-k) = -conj W_n^k);
+// k = 0 yields X[0] and X[h] from Z[0] alone, 2k = h a single bin.  `total` = batch * (h/2 + 1).
 template <typename T>
 FFT_KERNEL void FFT_LAUNCH_BOUNDS(256) r2c_split_kernel(const cpx<T>* z, cpx<T>* x_out, const cpx<T>* w, int h, long long total) {
     const long long stride = FFT_NBLOCKS * FFT_NTHREADS;
+    const int hp = h / 2 + 1;
     for (long long i = FFT_BID * FFT_NTHREADS + FFT_TID; i < total; i += stride) {
-        const long long b = i / (h + 1);
-        const int k = (int)(i - b * (h + 1));
+        const long long b = i / hp;
+        const int k = (int)(i - b * hp);
         const cpx<T>* zb = z + b * h;
-        const cpx<T> a = zb[k == h ? 0 : k];
-        const cpx<T> c0 = zb[(k == 0 || k == h) ? 0 : h - k];
+        cpx<T>* xb = x_out + b * (h + 1);
+        const cpx<T> a = zb[k];
+        const cpx<T> c0 = zb[k == 0 ? 0 : h - k];
         const cpx<T> c = mk<T>(c0.re, -c0.im);                                   // conj(Z[h-k])
         const cpx<T> e = cscale(cadd(a, c), (T)0.5);
         const cpx<T> o = mul_neg_i(cscale(csub(a, c), (T)0.5));                  // (a - c) / (2i)
-        x_out[b * (h + 1) + k] = cadd(e, cmul(w[k], o));
+        const cpx<T> t = cmul(w[k], o);
+        xb[k] = cadd(e, t);
+        if (2 * k != h) {
+            const cpx<T> m = csub(e, t);
+            xb[h - k] = mk<T>(m.re, -m.im);
+        }
     }
 }
 
 // The inverse of the split: X[0..h] (Hermitian half spectrum of a real signal of even length n = 2h) -> Z[0..h-1] with
-//   E[k] = (X[k] + conj(X[h-k])) / 2,  O[k] = (X[k] - conj(X[h-k])) / 2 * conj(W_n^k),  Z[k] = E[k] + i O[k];
-// the inverse complex transform of length h (scaled by 1/h like every inverse here) then returns the n real samples.
+//   E[k] = (X[k] + conj(X[h-k])) / 2,  O[k] = (X[k] - conj(X[h-k])) / 2 * conj(W_n^k),  Z[k] = E[k] + i O[k],  Z[h-k] = conj(E[k] - i O[k])
+// (one thread per pair, `total` = batch * (h/2 + 1)); the inverse complex transform of length h (scaled by 1/h like every inverse
+// here) then returns the n real samples.
 template <typename T>
 FFT_KERNEL void FFT_LAUNCH_BOUNDS(256) c2r_merge_kernel(const cpx<T>* x_in, cpx<T>* z, const cpx<T>* w, int h, long long total) {
     const long long stride = FFT_NBLOCKS * FFT_NTHREADS;
+    const int hp = h / 2 + 1;
     for (long long i = FFT_BID * FFT_NTHREADS + FFT_TID; i < total; i += stride) {
-        const long long b = i / h;
-        const int k = (int)(i - b * h);
+        const long long b = i / hp;
+        const int k = (int)(i - b * hp);
         const cpx<T>* xb = x_in + b * (h + 1);
+        cpx<T>* zb = z + b * h;
         const cpx<T> a = xb[k];
         const cpx<T> c0 = xb[h - k];
         const cpx<T> c = mk<T>(c0.re, -c0.im);
         const cpx<T> e = cscale(cadd(a, c), (T)0.5);
-        const cpx<T> o = cmul_conj(cscale(csub(a, c), (T)0.5), w[k]);
-        z[b * h + k] = cadd(e, mul_pos_i(o));
+        const cpx<T> io = mul_pos_i(cmul_conj(cscale(csub(a, c), (T)0.5), w[k]));
+        zb[k] = cadd(e, io);
+        if (k != 0 && 2 * k != h) {
+            const cpx<T> m = csub(e, io);
+            zb[h - k] = mk<T>(m.re, -m.im);
+        }
     }
 }
 

@@ -164,7 +164,7 @@ class RealPlan {
     void execute_r2c(const T* x, cpx<T>* X, int nb) {
         if (even()) {
             core.execute(reinterpret_cast<const cpx<T>*>(x), work, nb);
-            launch_flat(rt, fftk::r2c_split_kernel<T>, (long long)nb * (h + 1), (const cpx<T>*)work, X, (const cpx<T>*)w, h, (long long)nb * (h + 1));
+            launch_flat(rt, fftk::r2c_split_kernel<T>, (long long)nb * (h / 2 + 1), (const cpx<T>*)work, X, (const cpx<T>*)w, h, (long long)nb * (h / 2 + 1));
         } else {
             launch_flat(rt, fftk::real_to_complex_kernel<T>, (long long)nb * n, x, work, (long long)nb * n);
             core.execute(work, work, nb);
@@ -174,7 +174,7 @@ class RealPlan {
     // c2r: X complex [nb][n/2 + 1] (Hermitian half) -> x real [nb][n], scaled by 1/n
     void execute_c2r(const cpx<T>* X, T* x, int nb) {
         if (even()) {
-            launch_flat(rt, fftk::c2r_merge_kernel<T>, (long long)nb * h, X, work, (const cpx<T>*)w, h, (long long)nb * h);
+            launch_flat(rt, fftk::c2r_merge_kernel<T>, (long long)nb * (h / 2 + 1), X, work, (const cpx<T>*)w, h, (long long)nb * (h / 2 + 1));
             core.execute(work, reinterpret_cast<cpx<T>*>(x), nb);
         } else {
             launch_flat(rt, fftk::hermitian_extend_kernel<T>, (long long)nb * n, X, work, n, (long long)nb * n);
