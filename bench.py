@@ -260,6 +260,50 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
+def live_pmc_traffic(workload, kernel_substr):
+    """roofline.traffic measured in THIS run (round-2 review: the committed figure is builder-side): two child runs of this command under
+    `rocprofv3 --pmc` -- counters only, one counter per pass, never combined with tracing -- and the average of the dominant kernel's
+    dispatches.  Bytes across the L2's memory side per launch: FETCH_SIZE (KB, 128-byte requests tallied at 64: x 2, MI355X_MICROARCH.md HBM
+    section) + WRITE_SIZE (KB).  Returns (bytes, read bytes, written bytes) or None when rocprofv3 is missing or a pass fails."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    tool = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(tool):
+        return None
+    vals = {}
+    for cset in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="fft_pmc_", dir="/tmp")
+        try:
+            cmd = [tool, "--pmc", cset, "-d", d, "--output-format", "csv", "--", sys.executable, os.path.abspath(__file__),
+                   "--workload", workload, "--steps", "3", "--warmup", "1", "--no-check", "--no-cpu-baseline", "--no-secondary", "--no-live-traffic"]
+            env = dict(os.environ)
+            env["TMPDIR"] = "/tmp"
+            for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+                env.pop(k, None)
+            r = subprocess.run(cmd, cwd="/tmp", env=env, timeout=420, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            if r.returncode != 0:
+                return None
+            tot, cnt = 0.0, 0
+            for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        if kernel_substr in row["Kernel_Name"] and row["Counter_Name"] == cset:
+                            tot += float(row["Counter_Value"])
+                            cnt += 1
+            if not cnt:
+                return None
+            vals[cset] = tot / cnt
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    rd, wr = vals["FETCH_SIZE"] * 2048.0, vals["WRITE_SIZE"] * 1024.0
+    return rd + wr, rd, wr
+
+
 def device_copy_gbs(torch, x, y, iters=10):
     """What a plain device copy of the same buffers achieves on THIS box (read + written bytes per second): the
     practical ceiling the guide quotes at 6.29 TB/s; roofline.frac_of_copy = achieved / this."""
@@ -291,6 +335,8 @@ def main():
                     help="untimed executes BEFORE the W warmup steps until this much wall time has passed: a fresh process starts at idle "
                          "clocks and the first few ms-sized steps would otherwise be timed on the ramp (0 = off)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the fp64 2^19 secondary line and the device copy")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not measure roofline.traffic live (two rocprofv3 --pmc child runs of this command); use profiles/pmc_traffic.json")
     ap.add_argument("--cpu-baseline-only", action="store_true", help="(internal) print the CPU baseline JSON for --workload and exit")
     ap.add_argument("--dry-run", action="store_true",
                     help="(tests) launcher rehearsal without a GPU: the ranks meet over gloo, reduce a dummy time and rank 0 prints n_gpus")
@@ -436,6 +482,7 @@ def main():
     # formed and the multi-pass fallback queued behind it did; -1: the plan has no team kernel (multi-pass schedule)
     team_status = plan.team_status()
     team = info.team_tiles > 0 and team_status == 0
+    team_kernel_name = {1: "team_fft_kernel", 2: "team_defer_kernel", 3: "team_quad_kernel"}.get(info.team_kernel) if team else None
     # ---- per-launch kernel durations, one more execute with a HIP event after every launch
     per_pass = []
     if not info.bluestein_m:
@@ -499,6 +546,17 @@ def main():
     except Exception:
         pass
 
+    traffic_source = "profiles/pmc_traffic.json (committed rocprofv3 --pmc summary, same kernel sources)" if traffic is not None else None
+    traffic_committed = traffic
+    if rank == 0 and world == 1 and team and team_kernel_name and not args.no_live_traffic:
+        live = live_pmc_traffic(args.workload, team_kernel_name)
+        if live:
+            traffic = live[0]
+            traffic_source = "live: two rocprofv3 --pmc child runs of this command (FETCH_SIZE x 2 + WRITE_SIZE, average per launch of %s)" % team_kernel_name
+            traffic_note = ("measured in this run: reads %.2f GB, writes %.2f GB per launch against %.2f GB algorithmic = %.2f x; committed summary: %s"
+                            % (live[1] / 1e9, live[2] / 1e9, 2.0 * n * esz * units_per_launch / 1e9, live[0] / (2.0 * n * esz * units_per_launch),
+                               ("%.2f GB" % (traffic_committed / 1e9)) if traffic_committed else "none for these sources"))
+
     result = {
         "metric": "Gpoint/s + achieved HBM GB/s, batched 1D c2c FFT at 1/2/4/8 MI355X",
         "value": value, "unit": "Gpoint/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -520,7 +578,7 @@ def main():
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
             "kernel": kernel_desc,
             "algorithmic_bytes_per_unit": 2.0 * n * esz,
             "units_per_launch_set": units_per_launch,
