@@ -61,6 +61,8 @@ inline T shfl_xor_any(T v, int mask) {
 #define FFT_XCC_ID(nteams) ((unsigned)((emu::blockIdx_.x + ((emu::xcc_skew && emu::blockIdx_.x == 0) ? 1u : 0u)) % (unsigned)(nteams)))
 #define FFT_ATOMIC_ADD_AGENT(p, v) __atomic_fetch_add((p), (v), __ATOMIC_SEQ_CST)
 #define FFT_ATOMIC_ADD_AGENT_RELAXED(p, v) __atomic_fetch_add((p), (v), __ATOMIC_SEQ_CST)
+#define FFT_ATOMIC_ADD_AGENT_RELEASE(p, v) __atomic_fetch_add((p), (v), __ATOMIC_SEQ_CST)
+#define FFT_FENCE_ACQUIRE_AGENT() __atomic_thread_fence(__ATOMIC_SEQ_CST)
 #define FFT_ATOMIC_LOAD_AGENT(p) __atomic_load_n((p), __ATOMIC_SEQ_CST)
 #define FFT_ATOMIC_STORE_AGENT(p, v) __atomic_store_n((p), (v), __ATOMIC_SEQ_CST)
 namespace emu {
@@ -165,6 +167,8 @@ __device__ __forceinline__ double fft_xor_exchange(double v, int mask, bool) { r
 #define FFT_ATOMIC_ADD_AGENT(p, v) __hip_atomic_fetch_add((p), (v), __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT)
 // ... without ordering (no L2 write-back / invalidate around it): a counter that guards no data (team_quad_kernel's work claims)
 #define FFT_ATOMIC_ADD_AGENT_RELAXED(p, v) __hip_atomic_fetch_add((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define FFT_ATOMIC_ADD_AGENT_RELEASE(p, v) __hip_atomic_fetch_add((p), (v), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT)
+#define FFT_FENCE_ACQUIRE_AGENT() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
 #define FFT_ATOMIC_LOAD_AGENT(p) __hip_atomic_load((p), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)
 #define FFT_ATOMIC_STORE_AGENT(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT)
 __device__ __forceinline__ unsigned fft_cas_agent(unsigned* p, unsigned expected, unsigned desired) {  // returns the value found

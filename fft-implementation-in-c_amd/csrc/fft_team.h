@@ -129,13 +129,15 @@ template <typename T>
 FFT_DEVICE void team_form(const TeamParams<T>& p, unsigned* sh) {
     FFT_TEST_DELAY();
     const unsigned xcc = FFT_XCC_ID(p.n_xcc);
-    const unsigned slot = FFT_ATOMIC_ADD_AGENT(&p.ctl[TEAM_CTL_COUNT + 32 * xcc], 1u);
-    FFT_ATOMIC_ADD_AGENT(&p.ctl[TEAM_CTL_REGISTERED], 1u);
+    // (my seat: relaxed; the RELEASE of the registration below orders it in front of that, the one acquire fence behind the poll loop
+    // orders every reader's counter loads behind every registration -- no cache maintenance per poll)
+    const unsigned slot = FFT_ATOMIC_ADD_AGENT_RELAXED(&p.ctl[TEAM_CTL_COUNT + 32 * xcc], 1u);
+    FFT_ATOMIC_ADD_AGENT_RELEASE(&p.ctl[TEAM_CTL_REGISTERED], 1u);
     const unsigned nblocks = (unsigned)FFT_NBLOCKS;
     unsigned ok = 0;
     const long long t0 = FFT_CLOCK();
     for (;;) {
-        const unsigned v = FFT_ATOMIC_LOAD_AGENT(&p.ctl[TEAM_CTL_REGISTERED]);
+        const unsigned v = FFT_L2_FLAG_LOAD(&p.ctl[TEAM_CTL_REGISTERED]);
         if (v == nblocks) { ok = 1; break; }
         if (v & TEAM_CTL_POISON) break;
         if (FFT_CLOCK() - t0 > p.form_timeout_ticks) {
@@ -145,12 +147,13 @@ FFT_DEVICE void team_form(const TeamParams<T>& p, unsigned* sh) {
         }
         FFT_SLEEP();
     }
+    FFT_FENCE_ACQUIRE_AGENT();
     unsigned xcc_rank = 0;  // my XCD's place among the XCDs the launch landed on
     if (ok) {  // every workgroup has registered: the per-XCD counts are final and the same for every reader
         // exactly n_xcc XCC ids must hold a full set of seats and no other id any workgroup.  WHICH ids is the hardware's
         // business: a partition of the device (DPX / QPX / CPX) need not number its XCDs from 0, so a team is
         // numbered by the RANK of its XCC id among the ids present, not by the id itself.
-        // (sixteen RELAXED device-scope loads, all in flight at once: the acquire load of REGISTERED above has ordered them behind every
+        // (sixteen RELAXED device-scope loads, all in flight at once: the acquire fence above has ordered them behind every
         // registration, and sixteen acquire loads in a row -- a memory round trip and a cache invalidate each -- made formation 40 us
         // of every launch, profiles/r3_quad_fill.txt)
         unsigned cnts[16];
