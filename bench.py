@@ -273,6 +273,10 @@ def live_pmc_traffic(workload, kernel_substr):
     tool = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(tool):
         return None
+    # never from inside a profiled run: a profiler's preloaded library is inherited by the child, and starting a second profiler from
+    # there is refused by the GPU boxes' exec guard (and would profile the profiler)
+    if "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.upper().startswith(("ROCPROF", "ROCP_", "ROCTX")) for k in os.environ):
+        return None
     vals = {}
     for cset in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="fft_pmc_", dir="/tmp")

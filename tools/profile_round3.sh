@@ -8,12 +8,12 @@ tag=${1:-r3}
 O=$R/gpurun_out/$tag
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $O/trace --output-format csv -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-secondary > $O/trace_bench.log 2>&1 || { tail -5 $O/trace_bench.log; exit 1; }
+rocprofv3 --kernel-trace --stats -d $O/trace --output-format csv -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-secondary --no-live-traffic > $O/trace_bench.log 2>&1 || { tail -5 $O/trace_bench.log; exit 1; }
 for wl in 1m 256k 64k; do
   i=0
   for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
     i=$((i+1))
-    timeout -k 10 300 rocprofv3 --pmc $set -d $O/pmc_${wl}_$i --output-format csv -- python3 $R/bench.py --workload $wl --steps 3 --warmup 1 --no-check --no-cpu-baseline --no-secondary > $O/pmc_${wl}_$i.log 2>&1 || { echo "pmc pass $wl $i failed"; tail -5 $O/pmc_${wl}_$i.log; exit 1; }
+    timeout -k 10 300 rocprofv3 --pmc $set -d $O/pmc_${wl}_$i --output-format csv -- python3 $R/bench.py --workload $wl --steps 3 --warmup 1 --no-check --no-cpu-baseline --no-secondary --no-live-traffic > $O/pmc_${wl}_$i.log 2>&1 || { echo "pmc pass $wl $i failed"; tail -5 $O/pmc_${wl}_$i.log; exit 1; }
   done
 done
 i=3
@@ -21,7 +21,7 @@ for set in "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_WRREQ_sum TCC_EA0_W
            "GRBM_GUI_ACTIVE SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
            "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS" ; do
   i=$((i+1))
-  timeout -k 10 300 rocprofv3 --pmc $set -d $O/pmc_1m_$i --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-check --no-cpu-baseline --no-secondary > $O/pmc_1m_$i.log 2>&1 || { echo "pmc pass 1m $i failed"; tail -5 $O/pmc_1m_$i.log; exit 1; }
+  timeout -k 10 300 rocprofv3 --pmc $set -d $O/pmc_1m_$i --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-check --no-cpu-baseline --no-secondary --no-live-traffic > $O/pmc_1m_$i.log 2>&1 || { echo "pmc pass 1m $i failed"; tail -5 $O/pmc_1m_$i.log; exit 1; }
 done
 cd $R
 for wl in 1m 64k 256k prime 1k; do
