@@ -208,7 +208,10 @@ __device__ __forceinline__ unsigned long long fft_scalar_load2_glc(const unsigne
 #define FFT_LDS_FRESH() asm volatile("" ::: "memory")
 #define FFT_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)  // the instruction scheduler moves nothing across this point
 #define FFT_WAIT_VM0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-#define FFT_SLEEP() __builtin_amdgcn_s_sleep(2)
+#ifndef FFT_SLEEP_N
+#define FFT_SLEEP_N 2  // (64-clock units between two polls of a team wait; 0, 1, 4 measured: tools/ab_quad.sh)
+#endif
+#define FFT_SLEEP() __builtin_amdgcn_s_sleep(FFT_SLEEP_N)
 #define FFT_CLOCK() ((long long)wall_clock64())
 #define FFT_UNIFORM(v) __builtin_amdgcn_readfirstlane(v)
 // LDS-DMA: 16 bytes per lane from global memory straight into LDS (global_load_lds_dwordx4), no VGPR destination.
