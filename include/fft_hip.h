@@ -179,7 +179,9 @@ int fft_gpu_set_policy_hip(int team_mode, int team_min_batch, int chunk_mb);
  * too), -1 the plan has no team kernel or it has never been launched */
 int fft_gpu_plan_team_status_hip(fft_gpu_plan_t plan);
 /* profiling: every workgroup of the team kernel logs its 100 MHz clock at its first `events` timeline events into
- * d_trace[workgroup * events + i] (256 * events * 8 bytes of device memory owned by the caller); NULL switches it off */
+ * d_trace[workgroup * events + i] (256 * events * 8 bytes of device memory owned by the caller); NULL switches it off.
+ * team_quad_kernel keeps the last two slots for itself: [events - 2] = the workgroup's clock at kernel entry, [events - 1] =
+ * (team << 8) | seat (tools/quad_trace.py) */
 int fft_gpu_plan_team_trace_hip(fft_gpu_plan_t plan, void* d_trace, int events);
 /* `iters` back-to-back executes bracketed by hipEvents recorded on the plan's stream */
 int fft_gpu_execute_timed_hip(fft_gpu_plan_t plan, const void* d_in, void* d_out, int iters, float* elapsed_ms);
