@@ -44,6 +44,8 @@
 // cache-policy bits on the streams (+-0; without `nt` -7 %), round 1's values sent behind the first team wait of the exchange instead
 // of behind a wait of their own in the combine (-2.5 %), the next transform's index read by every wave with a scalar load of its own in
 // round 3 (-10 %: 256 waves per XCD queue behind the result stores; the index now rides on the team wait's poll, see `pub`).
+// Kept although within the noise (profiles/r3_ab_early_prefetch.txt: +0.5 % at 2^20, +1 % at 2^18 / 2^16): the next transform's first two
+// chunks are requested as soon as their LDS images are free (QUAD_EARLY_CHUNK0 / 1) -- the result stores, not the request time, hold them up.
 #ifndef QUAD_LDS_SINGLE  // 1: the stage exchanges use single ds_read_b64 / ds_write_b64 (FFT_LDS_LD64 / ST64), never the fused forms (+5 %)
 #define QUAD_LDS_SINGLE 1
 #endif
@@ -69,6 +71,12 @@ FFT_DEVICE void quad_st(cpx<T>* p, cpx<T> v) {
 }  // namespace fftk
 #ifndef QUAD_PAIR_DPP    // 1: the row-pair exchange in front of a 16-byte store as v_cndmask_b32_dpp (select and lane swap in one instruction)
 #define QUAD_PAIR_DPP 1
+#endif
+#ifndef QUAD_EARLY_CHUNK0  // 1: chunk 0 of the team's next transform is requested in round 2 (behind the request for round 3's image), not in round 3
+#define QUAD_EARLY_CHUNK0 1
+#endif
+#ifndef QUAD_EARLY_CHUNK1  // 1: chunk 1 of the team's next transform is requested in round 3 too (behind the round's last image reads), not at chunk 0's barrier
+#define QUAD_EARLY_CHUNK1 1
 #endif
 #ifndef QUAD_FINE_TRACE  // profiling builds only: time stamps inside the column chunks of transform 3 (tools/quad_fine.py)
 #define QUAD_FINE_TRACE 0
@@ -413,7 +421,7 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
             // my pieces of the chunk have landed ... everybody's have; the other image was last read before this barrier.
             // What may still be in flight behind chunk 0's DMA are the previous transform's 4 E / 2 result stores (vmcnt counts
             // in issue order)
-            if (it > 0 && a == 0) FFT_WAIT_VM_LE(4 * E / V);
+            if (it > 0 && a == 0) FFT_WAIT_VM_LE(4 * E / V + (QUAD_EARLY_CHUNK1 ? NCH : 0));  // (+ chunk 1's pieces, requested in round 3)
             else FFT_WAIT_VM0();
             FFT_SYNC_LDS();
             ev();
@@ -421,7 +429,7 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
             // counts the previous transform's result stores (vmcnt counts in issue order: in front of it the claim would make its wave
             // wait for the first of those stores, and the team for that wave: -10 % at n = 2^20)
             if (a == 3 && p.dynamic && s == 0 && tid == 0) claimed = FFT_ATOMIC_ADD_AGENT_RELAXED(claim, 1u) + (unsigned)n_teams;
-            if (a + 1 < 4) dma_chunk(inb, a + 1, (a + 1) & 1);
+            if (a + 1 < 4 && !(QUAD_EARLY_CHUNK1 && a == 0 && it > 0)) dma_chunk(inb, a + 1, (a + 1) & 1);
             cpx<T>* img = reinterpret_cast<cpx<T>*>(img_b[a & 1]);
             int t = tid0;
             FFT_OPAQUE(t);
@@ -570,11 +578,13 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
         FFT_UNROLL
         for (int r = 0; r < 4; r++) {
             if (r == 1 && p.dynamic && s == 0 && tid == 0) FFT_L2_FLAG_STORE(pub, claimed + 1u);
-            FFT_WAIT_VM0();  // the round's image has landed ...
+            // the round's image has landed ... (round 3: the next transform's chunk 0, requested behind it, may still fly: vmcnt counts in issue order)
+            if (QUAD_EARLY_CHUNK0 && r == 3 && nxt < p.nb) FFT_WAIT_VM_LE(NCH);
+            else FFT_WAIT_VM0();
             FFT_SYNC_LDS();  // ... everybody's of this workgroup
             arrive();  // L_r
             ev();
-            if (r == 3) {
+            if (!QUAD_EARLY_CHUNK0 && r == 3) {
                 learn_next();
                 if (nxt < p.nb) dma_chunk(p.in + nxt * n, 0, 0);  // image 0 was last read in round 2
             }
@@ -593,10 +603,18 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
             const int nr = t >> LOG2NR;
             cpx<T> v[E];
             quad_stage2_read<T, E, LOG2NR>(v, img, t & (NR - 1), nr);
+            if (QUAD_EARLY_CHUNK1 && r == 3 && nxt < p.nb) {
+                FFT_SYNC_LDS();  // everybody has read image 1 for the last time
+                dma_chunk(p.in + nxt * n, 1, 1);
+            }
             if (r < 3) {
                 wait_all(G + 2 * r + 3);  // everybody's values of round r + 1 are in L2
                 ev();
                 dma_window(0, (r + 1) & 1);
+                if (QUAD_EARLY_CHUNK0 && r == 2) {  // image 0 was read for the last time in front of that wait's barrier
+                    learn_next();
+                    if (nxt < p.nb) dma_chunk(p.in + nxt * n, 0, 0);
+                }
             }
             quad_stage2_dft<T, E, RB>(v);
             const int apr = (r - sigma) & 3;  // the class this round delivered to my row
@@ -610,11 +628,13 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
         FFT_UNROLL
         for (int r = 0; r < 4; r++) {
             if (r == 1 && p.dynamic && s == 0 && tid == 0) FFT_L2_FLAG_STORE(pub, claimed + 1u);
-            FFT_WAIT_VM0();  // the round's image has landed and my round-(r + 1) values are in L2 ...
+            // the round's image has landed and my round-(r + 1) values are in L2 ... (round 3: the next transform's chunk 0 may still fly)
+            if (QUAD_EARLY_CHUNK0 && r == 3 && nxt < p.nb) FFT_WAIT_VM_LE(NCH);
+            else FFT_WAIT_VM0();
             FFT_SYNC_LDS();  // ... everybody's
             arrive();  // arrival G + r + 2 (r = 3: G + 5, "my image of round 3 has landed")
             ev();
-            if (r == 3) {
+            if (!QUAD_EARLY_CHUNK0 && r == 3) {
                 learn_next();
                 if (nxt < p.nb) dma_chunk(p.in + nxt * n, 0, 0);  // image 0 was last read in round 2
             }
@@ -627,6 +647,10 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
             const int nr = t >> LOG2NR;
             cpx<T> v[E];
             quad_stage2_read<T, E, LOG2NR>(v, img, t & (NR - 1), nr);
+            if (QUAD_EARLY_CHUNK1 && r == 3 && nxt < p.nb) {
+                FFT_SYNC_LDS();  // everybody has read image 1 for the last time
+                dma_chunk(p.in + nxt * n, 1, 1);
+            }
             if (r < 3) {
                 // the next round's image is requested NOW (the other image was last read in round r - 1) and flies under this
                 // round's second stage; behind it the values of round r + 2, into the slot this round's image came from
@@ -635,6 +659,10 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
                 ev();
                 dma_window((r + 1) & 1, (r + 1) & 1);
                 if (r < 2) send(r + 2);
+                if (QUAD_EARLY_CHUNK0 && r == 2) {  // image 0 was read for the last time in front of that wait's barrier
+                    learn_next();
+                    if (nxt < p.nb) dma_chunk(p.in + nxt * n, 0, 0);
+                }
             }
             quad_stage2_dft<T, E, RB>(v);
             const int apr = (r - sigma) & 3;  // the class this round delivered to my row
