@@ -260,13 +260,26 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
+def pmc_average(out_dir, kernel_substr, counter):
+    """Average of `counter` over the dispatches of the kernels whose name contains `kernel_substr`, from the counter_collection CSVs
+    rocprofv3 --pmc leaves under out_dir (columns Kernel_Name, Counter_Name, Counter_Value); None when there is no such row."""
+    import csv
+    import glob
+    tot, cnt = 0.0, 0
+    for f in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                if kernel_substr in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                    tot += float(row["Counter_Value"])
+                    cnt += 1
+    return tot / cnt if cnt else None
+
+
 def live_pmc_traffic(workload, kernel_substr):
     """roofline.traffic measured in THIS run (round-2 review: the committed figure is builder-side): two child runs of this command under
     `rocprofv3 --pmc` -- counters only, one counter per pass, never combined with tracing -- and the average of the dominant kernel's
     dispatches.  Bytes across the L2's memory side per launch: FETCH_SIZE (KB, 128-byte requests tallied at 64: x 2, MI355X_MICROARCH.md HBM
     section) + WRITE_SIZE (KB).  Returns (bytes, read bytes, written bytes) or None when rocprofv3 is missing or a pass fails."""
-    import csv
-    import glob
     import shutil
     import subprocess
     import tempfile
@@ -290,16 +303,10 @@ def live_pmc_traffic(workload, kernel_substr):
             r = subprocess.run(cmd, cwd="/tmp", env=env, timeout=420, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
             if r.returncode != 0:
                 return None
-            tot, cnt = 0.0, 0
-            for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
-                with open(f) as fh:
-                    for row in csv.DictReader(fh):
-                        if kernel_substr in row["Kernel_Name"] and row["Counter_Name"] == cset:
-                            tot += float(row["Counter_Value"])
-                            cnt += 1
-            if not cnt:
+            avg = pmc_average(d, kernel_substr, cset)
+            if avg is None:
                 return None
-            vals[cset] = tot / cnt
+            vals[cset] = avg
         except Exception:
             return None
         finally:

@@ -104,3 +104,20 @@ def test_bench_refuses_a_world_that_is_not_gpus():
     bench = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")
     r = subprocess.run([sys.executable, bench, "--gpus", "2", "--dry-run"], capture_output=True, text=True, timeout=120, env=env)
     assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
+
+
+def test_bench_pmc_average_reads_rocprofv3_counter_csv(tmp_path):
+    """bench.py's live roofline.traffic: the per-dispatch average of one counter for the dominant kernel, from the CSV layout rocprofv3
+    --pmc writes (other kernels and other counters in the same file are ignored; no matching row -> None -> the committed figure is used)."""
+    import bench
+    d = tmp_path / "run" / "host"
+    d.mkdir(parents=True)
+    (d / "123_counter_collection.csv").write_text(
+        '"Correlation_Id","Dispatch_Id","Agent_Id","Queue_Id","Process_Id","Thread_Id","Grid_Size","Kernel_Id","Kernel_Name","Workgroup_Size","LDS_Block_Size","Scratch_Size","VGPR_Count","Accum_VGPR_Count","SGPR_Count","Counter_Name","Counter_Value","Start_Timestamp","End_Timestamp"\n'
+        '1,1,0,1,7,7,131072,5,"void fftk::team_quad_kernel<float, 16, 4, 4, 10, 10, 5, 2>(fftk::TeamParams<float>)",512,0,0,240,0,96,"FETCH_SIZE",2500000.0,1,2\n'
+        '2,2,0,1,7,7,131072,5,"void fftk::team_quad_kernel<float, 16, 4, 4, 10, 10, 5, 2>(fftk::TeamParams<float>)",512,0,0,240,0,96,"FETCH_SIZE",2600000.0,3,4\n'
+        '3,3,0,1,7,7,1024,6,"void fftk::tile_fft_kernel<float, 8, 1, 0, 0, 0, true, 2563, 0>(fftk::TileParams<float>)",512,0,0,120,0,96,"FETCH_SIZE",11.0,5,6\n'
+        '4,4,0,1,7,7,131072,5,"void fftk::team_quad_kernel<float, 16, 4, 4, 10, 10, 5, 2>(fftk::TeamParams<float>)",512,0,0,240,0,96,"WRITE_SIZE",9.0,7,8\n')
+    assert bench.pmc_average(str(tmp_path), "team_quad_kernel", "FETCH_SIZE") == 2550000.0
+    assert bench.pmc_average(str(tmp_path), "team_quad_kernel", "WRITE_SIZE") == 9.0
+    assert bench.pmc_average(str(tmp_path), "team_defer_kernel", "FETCH_SIZE") is None
