@@ -554,6 +554,37 @@ def test_team_kernel_vs_oracle(gpu_lib, monkeypatch, log2n, dtype):
     out.free()
 
 
+@pytest.mark.parametrize("log2n,dtype", [(20, np.complex64), (19, np.complex64), (18, np.complex64), (17, np.complex64), (16, np.complex64),
+                                         (15, np.complex64), (16, np.complex128), (15, np.complex128), (14, np.complex128)])
+def test_default_policy_switches_schedule_at_the_measured_crossover(gpu_lib, log2n, dtype):
+    """Default policy (round 3: profiles/r3_batch_crossover.txt): the one-round-trip kernel runs from 128 MiB per execute (n = 2^20, 2^19) /
+    256 MiB (the other sizes), the multi-pass schedule below; one transform short of the crossover and one past it, out of place and in
+    place, EVERY transform against numpy (the team kernels take their transforms by claiming: no fixed transform -> team map)."""
+    import fftlib
+    fftlib.set_policy(team=1, min_batch=0)
+    n = 1 << log2n
+    esz = np.dtype(dtype).itemsize
+    mib = 128 if (dtype == np.complex64 and log2n >= 19) else 256
+    mb = (mib << 20) // (n * esz)
+    x8 = lcg(n, 8, dtype, seed=40 + log2n)
+    ref = np.fft.fft(x8.astype(np.complex128), axis=1)
+    tol = TIGHT[np.dtype(dtype)]  # (and with it the contractual TOL)
+    for batch, want in ((mb - 1, -1), (mb + 1, 0)):
+        x = x8[np.arange(batch) % 8]
+        buf, out = fftlib.DeviceBuffer(x.nbytes), fftlib.DeviceBuffer(x.nbytes)
+        plan = fftlib.Plan(n, batch, -1, dtype)
+        for inplace in (False, True):
+            buf.upload(x)
+            plan.execute_ptr(buf.ptr, buf.ptr if inplace else out.ptr)
+            assert plan.team_status() == want, (log2n, batch, plan.team_status())
+            y = (buf if inplace else out).download(x.shape, dtype)
+            err = max(float(np.linalg.norm(y[i] - ref[i % 8]) / np.linalg.norm(ref[i % 8])) for i in range(batch))
+            assert err <= tol, (log2n, batch, inplace, err)
+        plan.destroy()
+        buf.free()
+        out.free()
+
+
 def test_team_kernel_default_policy_and_full_size(gpu_lib, monkeypatch):
     """BASELINE configs[2] as bench.py runs it: N = 2^20 fp32 x 512 takes the team kernel by default; every one of
     the 512 spectra is checked against the analytic two-tone answer; a batch of 8 (below the measured crossover of 16
