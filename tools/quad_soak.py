@@ -24,7 +24,7 @@ def main():
         x = np.tile(x8, (batch // 8, 1))
         a, b = fftlib.DeviceBuffer(x.nbytes), fftlib.DeviceBuffer(x.nbytes)
         a.upload(x)
-        plan = fftlib.Plan(n, batch + 3 if False else batch, -1, dtype)
+        plan = fftlib.Plan(n, batch, -1, dtype)
         plan.execute_ptr(a.ptr, b.ptr)
         assert plan.team_status() == 0, (log2n, plan.team_status())
         y0 = b.download(x.shape, dtype)
