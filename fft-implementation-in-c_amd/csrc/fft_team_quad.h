@@ -79,6 +79,9 @@ FFT_DEVICE void quad_st(cpx<T>* p, cpx<T> v) {
 #ifndef QUAD_EARLY_CHUNK1  // 1: chunk 1 of the team's next transform is requested in round 3 too (behind the round's last image reads), not at chunk 0's barrier
 #define QUAD_EARLY_CHUNK1 1
 #endif
+#ifndef QUAD_ABL  // timing experiments only (tools/ab_quad.sh variants; results invalid): 1 no result stores, 2 no stage barrier in the column
+#define QUAD_ABL 0  // step, 4 none in the row step, 8 no column-step arithmetic, 16 no window stores, 32 no row-step arithmetic
+#endif
 #ifndef QUAD_FINE_TRACE  // profiling builds only: time stamps inside the column chunks of transform 3 (tools/quad_fine.py)
 #define QUAD_FINE_TRACE 0
 #endif
@@ -458,12 +461,17 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
             quad_stage2_dft<T, E, RA>(v);
             fine(0);  // 7: dft
 #else
-            quad_stage1<T, E, RA, LOG2NC, LOG2L1, true>(img, wlA, t & (NC - 1), t >> LOG2NC, p.inverse != 0);
-            FFT_SYNC_LDS();
+            if (!(QUAD_ABL & 8) || p.nb < 0) quad_stage1<T, E, RA, LOG2NC, LOG2L1, true>(img, wlA, t & (NC - 1), t >> LOG2NC, p.inverse != 0);
+            if (!(QUAD_ABL & 2) || p.nb < 0) FFT_SYNC_LDS();
             FFT_OPAQUE(t);
             const int g = t & (RA - 1), c2 = ap + 4 * sender_cc(t);
-            quad_stage2_read<T, E, LOG2NC>(v, img, quad_rot<RA, NC>(c2, g), g);
-            quad_stage2_dft<T, E, RA>(v);
+            if (!(QUAD_ABL & 8) || p.nb < 0) {
+                quad_stage2_read<T, E, LOG2NC>(v, img, quad_rot<RA, NC>(c2, g), g);
+                quad_stage2_dft<T, E, RA>(v);
+            } else {
+                FFT_UNROLL
+                for (int k = 0; k < E; k++) v[k] = mk<T>((T)(k + a), (T)t);
+            }
 #endif
             if (a == 0) {
                 FFT_UNROLL
@@ -510,7 +518,7 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
                     k1 = (g & ~1) + E * (2 * i + (odd ? 1 : 0)) + MA * q;
                 }
                 const int dst_seat = k1 >> LOG2NR, rho = k1 & (NR - 1);
-                *reinterpret_cast<vec16<T>*>(wslot + (size_t)dst_seat * IMG + (size_t)(((bprime << LOG2NR) + rho) * SZ)) = v;
+                if (!(QUAD_ABL & 16) || p.nb < 0) *reinterpret_cast<vec16<T>*>(wslot + (size_t)dst_seat * IMG + (size_t)(((bprime << LOG2NR) + rho) * SZ)) = v;
             }
             }
         };
@@ -642,12 +650,16 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
             cpx<T>* img = reinterpret_cast<cpx<T>*>(img_b[r & 1]);
             int t = tid0;
             FFT_OPAQUE(t);
-            quad_stage1<T, E, RB, LOG2NR, LOG2L2, false>(img, wlB, t & (NR - 1), t >> LOG2NR, false);
-            FFT_SYNC_LDS();
+            if (!(QUAD_ABL & 32) || p.nb < 0) quad_stage1<T, E, RB, LOG2NR, LOG2L2, false>(img, wlB, t & (NR - 1), t >> LOG2NR, false);
+            if (!(QUAD_ABL & 4) || p.nb < 0) FFT_SYNC_LDS();
             FFT_OPAQUE(t);
             const int nr = t >> LOG2NR;
             cpx<T> v[E];
-            quad_stage2_read<T, E, LOG2NR>(v, img, t & (NR - 1), nr);
+            if (!(QUAD_ABL & 32) || p.nb < 0) quad_stage2_read<T, E, LOG2NR>(v, img, t & (NR - 1), nr);
+            else {
+                FFT_UNROLL
+                for (int k = 0; k < E; k++) v[k] = mk<T>((T)(k + r), (T)t);
+            }
             if (QUAD_EARLY_CHUNK1 && r == 3 && nxt < p.nb) {
                 FFT_SYNC_LDS();  // everybody has read image 1 for the last time
                 dma_chunk(p.in + nxt * n, 1, 1);
@@ -665,7 +677,7 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
                     if (nxt < p.nb) dma_chunk(p.in + nxt * n, 0, 0);
                 }
             }
-            quad_stage2_dft<T, E, RB>(v);
+            if (!(QUAD_ABL & 32) || p.nb < 0) quad_stage2_dft<T, E, RB>(v);
             const int apr = (r - sigma) & 3;  // the class this round delivered to my row
             if (apr != 0) quad_twiddle_kb<T, E, RB, LOG2L2>(zt[r], v, wlB, apr, nr, 0);  // W_L2^(apr kb): < 3 MB
             else {
@@ -723,6 +735,7 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
                     quad_pair<T>(y[0][ka], y[1][ka], odd, v);
                     const long long k2 = (odd ? quad_kb<E, RB>(nr, 2 * i + 1) : quad_kb<E, RB>(nr, 2 * i)) + MB * ka;
                     vec16<T>* const dst = reinterpret_cast<vec16<T>*>(line0 + (k2 << LOG2L1));
+                    if ((QUAD_ABL & 1) && p.nb >= 0) continue;
                     if (p.nt_mask & 2) FFT_STORE16_NT(dst, v);
                     else *dst = v;
                 }
