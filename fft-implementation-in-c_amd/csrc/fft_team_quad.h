@@ -79,6 +79,9 @@ FFT_DEVICE void quad_st(cpx<T>* p, cpx<T> v) {
 #ifndef QUAD_EARLY_CHUNK1  // 1: chunk 1 of the team's next transform is requested in round 3 too (behind the round's last image reads), not at chunk 0's barrier
 #define QUAD_EARLY_CHUNK1 1
 #endif
+#ifndef QUAD_DEFER_STORES  // 1: a transform's result stores go out in four parts from the column step of the team's NEXT transform (see `final_part`).
+#define QUAD_DEFER_STORES 0  // Measured (profiles/r4_ab_defer_stores.txt, r4_ab_store_split.txt, r4_ab_defer_late.txt): +1.3 % at n = 2^20, +-0 below: off
+#endif
 #ifndef QUAD_ABL  // timing experiments only (tools/ab_quad.sh variants; results invalid): 1 no result stores, 2 no stage barrier in the column
 #define QUAD_ABL 0  // step, 4 none in the row step, 8 no column-step arithmetic, 16 no window stores, 32 no row-step arithmetic
 #endif
@@ -398,6 +401,69 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
         ck[k] = mk<T>(pw4 == 0 ? p.scale : pw4 == 2 ? -p.scale : (T)0, pw4 == 1 ? p.scale : pw4 == 3 ? -p.scale : (T)0);
     }
 
+    // ---- final radix-4 over the rounds, modulation, transposed store: X[k1 + L1 k2], k1 = NR s + rho, k2 = kb + MB ka; the
+    // lanes of rows rho, rho ^ 1 pair up so that every store is 16 bytes and every wave instruction writes whole NR-row
+    // segments.  The stores are the most expensive single item of a transform (profiles/r4_price_list.txt: without them the launch
+    // takes 2.16 instead of 2.55 ms at n = 2^20 x 512): 8 MiB per XCD in one burst is more than the L2 buffers, the XCD's write port
+    // (~ 1.1 TB/s) then paces the store instructions, and every wave of the CU sits in their issue for 5.5 - 7.5 of the transform's 39 us.
+    // QUAD_DEFER_STORES sends part `a` of four (the store groups a NP / 4 .. (a + 1) NP / 4) out in front of column chunk a of the team's
+    // NEXT transform (part a frees the 2 E registers chunk a's results need).  That moves the burst, it does not hide it: the port paces
+    // the stores wherever they are issued, and a wave that waits in a store's issue keeps the other seven at the next barrier (+1.3 %;
+    // cut into slices spread over the chunk's arithmetic, or the last part under the first team wait: +-0 / worse -- the registers spill).
+    cpx<T> zt[4][E];
+    constexpr int NP = (V == 1) ? E : E / 2;  // store groups of a thread: one value (fp64) or one value pair (fp32) x the 4 outputs of the radix-4
+    cpx<T> yk[2][4];
+    auto final_part = [&](int a, cpx<T>* outb) __attribute__((always_inline)) {
+        int t = tid0;
+        FFT_OPAQUE(t);
+        const int ncol = t & (NR - 1), nr = t >> LOG2NR;
+        const bool odd = (ncol & 1) != 0;
+        cpx<T>* const line0 = outb + NR * s + (ncol & ~1);
+        FFT_UNROLL
+        for (int i = 0; i < NP; i++) {
+            if (i < a * NP / 4 || i >= (a + 1) * NP / 4) continue;
+            if constexpr (V == 1) {  // fp64: every value is a 16-byte store of its own, a wave instruction writes NR-row segments all the same
+                FFT_UNROLL
+                for (int r = 0; r < 4; r++) yk[0][r] = zt[r][i];
+                dft_inplace<T, 4>(yk[0]);
+                FFT_UNROLL
+                for (int ka = 0; ka < 4; ka++) {
+                    vec16<T> v;
+                    v.c[0] = cmul(yk[0][ka], ck[ka]);
+                    if (p.inverse) v.c[0] = cswap(v.c[0]);
+                    const long long k2 = quad_kb<E, RB>(nr, i) + MB * ka;
+                    vec16<T>* const dst = reinterpret_cast<vec16<T>*>(outb + NR * s + ncol + (k2 << LOG2L1));
+                    if ((QUAD_ABL & 1) && p.nb >= 0) continue;
+                    if (p.nt_mask & 2) FFT_STORE16_NT(dst, v);
+                    else *dst = v;
+                }
+            } else {
+                FFT_UNROLL
+                for (int h = 0; h < 2; h++) {
+                    FFT_UNROLL
+                    for (int r = 0; r < 4; r++) yk[h][r] = zt[r][2 * i + h];
+                    dft_inplace<T, 4>(yk[h]);
+                    FFT_UNROLL
+                    for (int r = 0; r < 4; r++) {
+                        yk[h][r] = cmul(yk[h][r], ck[r]);
+                        if (p.inverse) yk[h][r] = cswap(yk[h][r]);
+                    }
+                }
+                FFT_UNROLL
+                for (int ka = 0; ka < 4; ka++) {
+                    vec16<T> v;
+                    quad_pair<T>(yk[0][ka], yk[1][ka], odd, v);
+                    const long long k2 = (odd ? quad_kb<E, RB>(nr, 2 * i + 1) : quad_kb<E, RB>(nr, 2 * i)) + MB * ka;
+                    vec16<T>* const dst = reinterpret_cast<vec16<T>*>(line0 + (k2 << LOG2L1));
+                    if ((QUAD_ABL & 1) && p.nb >= 0) continue;
+                    if (p.nt_mask & 2) FFT_STORE16_NT(dst, v);
+                    else *dst = v;
+                }
+            }
+        }
+    };
+    cpx<T>* out_prev = nullptr;  // QUAD_DEFER_STORES: where the results still in zt belong
+
     long long cur = team;  // the transform in hand
     dma_chunk(p.in + cur * n, 0, 0);
     for (int it = 0; cur < p.nb; it++) {
@@ -425,10 +491,17 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
             // my pieces of the chunk have landed ... everybody's have; the other image was last read before this barrier.
             // What may still be in flight behind chunk 0's DMA are the previous transform's 4 E / 2 result stores (vmcnt counts
             // in issue order)
+            if (QUAD_DEFER_STORES) {
+                // (chunk a's pieces are the youngest thing this thread has issued: its request follows part a - 1's stores -- that order measured
+                // faster than the request first --, so the wait for the pieces is a wait for everything)
+                FFT_WAIT_VM0();
+            } else {
             if (it > 0 && a == 0) FFT_WAIT_VM_LE(4 * E / V + (QUAD_EARLY_CHUNK1 ? NCH : 0));  // (+ chunk 1's pieces, requested in round 3)
             else FFT_WAIT_VM0();
+            }
             FFT_SYNC_LDS();
             ev();
+            if (QUAD_DEFER_STORES && it > 0) final_part(a, out_prev);  // the previous transform's results, part a
             // the claim for the transform after this one (used at the combine: its latency is hidden).  Issued HERE, behind the wait that
             // counts the previous transform's result stores (vmcnt counts in issue order: in front of it the claim would make its wave
             // wait for the first of those stores, and the team for that wave: -10 % at n = 2^20)
@@ -575,7 +648,6 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
             }
         }
         ev();
-        cpx<T> zt[4][E];
         wait_all(G + 1);
         ev();
         dma_window(0, 0);
@@ -686,64 +758,23 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
             }
         }
         }
-        // ---- final radix-4 over the rounds, modulation, transposed store: X[k1 + L1 k2], k1 = NR s + rho, k2 = kb + MB ka; the
-        // lanes of rows rho, rho ^ 1 pair up so that every store is 16 bytes and every wave instruction writes whole NR-row
-        // segments; the stores go out pair of values by pair of values between the butterflies
+        // ---- final radix-4 over the rounds and the result stores: now (QUAD_DEFER_STORES = 0) or from the next transform's column step
         ev();
-        {
-            int t = tid0;
-            FFT_OPAQUE(t);
-            const int ncol = t & (NR - 1), nr = t >> LOG2NR;
-            const bool odd = (ncol & 1) != 0;
-            cpx<T>* const line0 = outb + NR * s + (ncol & ~1);
-            if constexpr (V == 1) {  // fp64: every value is a 16-byte store of its own, a wave instruction writes NR-row segments all the same
-                FFT_UNROLL
-                for (int i = 0; i < E; i++) {
-                    cpx<T> y[4];
-                    FFT_UNROLL
-                    for (int r = 0; r < 4; r++) y[r] = zt[r][i];
-                    dft_inplace<T, 4>(y);
-                    FFT_UNROLL
-                    for (int ka = 0; ka < 4; ka++) {
-                        vec16<T> v;
-                        v.c[0] = cmul(y[ka], ck[ka]);
-                        if (p.inverse) v.c[0] = cswap(v.c[0]);
-                        const long long k2 = quad_kb<E, RB>(nr, i) + MB * ka;
-                        vec16<T>* const dst = reinterpret_cast<vec16<T>*>(outb + NR * s + ncol + (k2 << LOG2L1));
-                        if (p.nt_mask & 2) FFT_STORE16_NT(dst, v);
-                        else *dst = v;
-                    }
-                }
-            } else {
+        if (QUAD_DEFER_STORES) {
+            out_prev = outb;
+        } else {
             FFT_UNROLL
-            for (int i = 0; i < E / 2; i++) {
-                cpx<T> y[2][4];
-                FFT_UNROLL
-                for (int h = 0; h < 2; h++) {
-                    FFT_UNROLL
-                    for (int r = 0; r < 4; r++) y[h][r] = zt[r][2 * i + h];
-                    dft_inplace<T, 4>(y[h]);
-                    FFT_UNROLL
-                    for (int r = 0; r < 4; r++) {
-                        y[h][r] = cmul(y[h][r], ck[r]);
-                        if (p.inverse) y[h][r] = cswap(y[h][r]);
-                    }
-                }
-                FFT_UNROLL
-                for (int ka = 0; ka < 4; ka++) {
-                    vec16<T> v;
-                    quad_pair<T>(y[0][ka], y[1][ka], odd, v);
-                    const long long k2 = (odd ? quad_kb<E, RB>(nr, 2 * i + 1) : quad_kb<E, RB>(nr, 2 * i)) + MB * ka;
-                    vec16<T>* const dst = reinterpret_cast<vec16<T>*>(line0 + (k2 << LOG2L1));
-                    if ((QUAD_ABL & 1) && p.nb >= 0) continue;
-                    if (p.nt_mask & 2) FFT_STORE16_NT(dst, v);
-                    else *dst = v;
-                }
-            }
-            }
+            for (int a = 0; a < 4; a++) final_part(a, outb);
         }
         ev();
         cur = nxt;
+    }
+    if (QUAD_DEFER_STORES && out_prev) {  // the team's last transform
+        FFT_LDS_FRESH();
+        if (!sh[3]) {
+            FFT_UNROLL
+            for (int a = 0; a < 4; a++) final_part(a, out_prev);
+        }
     }
 }
 

@@ -304,6 +304,46 @@ def test_full_size_analytic_two_tone_config2(gpu_lib):
     buf.free()
 
 
+def _full_batch_through_shipped_schedule(n, batch, team_kernel=3):
+    """ONE execute of the whole batch on the default plan -- the schedule bench.py times: the plan must have chosen the one-round-trip
+    team kernel and the team kernel must have done the work (status 0, no fallback).  Every transform against its analytic spectrum
+    (X[f_b] = N, X[g_b] = N/2, all the energy in those two bins), the oracle on both sides of the boundaries of an 8-way batch shard."""
+    import fftlib
+    plan = fftlib.Plan(n, batch, -1, np.complex64)
+    info = plan.info()
+    assert info.team_kernel == team_kernel, (info.team_kernel, info.team_tiles)
+    buf = fftlib.DeviceBuffer(n * batch * 8)
+    x = O.gen_two_tone(n, 0, batch, np.complex64)
+    buf.upload(x)
+    plan.execute(buf, buf)
+    assert plan.team_status() == 0  # the team kernel ran (1: its fallback did)
+    y = buf.download((batch, n), np.complex64)
+    idx = np.arange(batch)
+    fg = np.array([O.two_tone_bins(n, b) for b in range(batch)])
+    assert np.max(np.abs(y[idx, fg[:, 0]] - n)) / n < 1e-4
+    assert np.max(np.abs(y[idx, fg[:, 1]] - n / 2)) / n < 1e-4
+    for b0 in range(0, batch, 256):  # (in slices: a complex128 copy of the whole batch would be 4 GiB)
+        tot = np.linalg.norm(y[b0:b0 + 256].astype(np.complex128), axis=1)
+        assert np.max(np.abs(tot / (n * np.sqrt(1.25)) - 1)) < 1e-5, b0
+    shard = batch // 8
+    for b in sorted({0, batch - 1} | {g * shard - 1 for g in range(1, 8)} | {g * shard for g in range(1, 8)}):
+        ref = O.oracle_fft(x[b].astype(np.complex128), -1, "dit")
+        assert rel(y[b], ref) <= 1e-4 and rel(y[b], ref) <= 2e-6, b
+    plan.destroy()
+    buf.free()
+
+
+def test_full_batch_config2_on_the_shipped_schedule(gpu_lib):
+    """BASELINE config 2 (N=65536 fp32, batch=4096) as bench.py runs it: one execute, team_quad_kernel on teams of 2 claiming their
+    transforms from the device counter (the chunked test above stays below the team kernel's crossover and runs the multi-pass plan)."""
+    _full_batch_through_shipped_schedule(65536, 4096)
+
+
+def test_full_batch_config4_shard_on_the_shipped_schedule(gpu_lib):
+    """BASELINE config 4's per-GPU shard (N=262144 fp32, 1024 of the 8192 transforms) in one execute: team_quad_kernel on teams of 8."""
+    _full_batch_through_shipped_schedule(1 << 18, 1024)
+
+
 def test_roundtrip_full_size_config3(gpu_lib):
     """BASELINE config 3 at FULL size (N=2^20 fp32, batch=512): forward then inverse on device returns the
     input (idempotence-style property), plus oracle parity on the first and last transform."""

@@ -14,7 +14,7 @@ done &&
 for nt in ${NTS-0 3}; do
   export FFT_HIP_TEAM_DEFER=0 FFT_HIP_TEAM_NT=$nt
   for set in FETCH_SIZE WRITE_SIZE; do
-    timeout -k 10 300 rocprofv3 --pmc $set -d $O/team_nt${nt}_$set --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-check --no-cpu-baseline > $O/team_nt${nt}_$set.log 2>&1 || exit 1
+    timeout -k 10 300 rocprofv3 --pmc $set -d $O/team_nt${nt}_$set --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-check --no-cpu-baseline --no-live-traffic > $O/team_nt${nt}_$set.log 2>&1 || exit 1
   done
   timeout -k 10 300 python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/team_nt${nt}_bench.log 2>&1 || exit 1
 done

@@ -12,7 +12,7 @@ export FFT_HIP_TEAM_DEFER=${DEFER-0}
 for cfg in ${CFGS-0:0 0:4 0:8 0:12 3:0 3:4 3:8}; do
   export FFT_HIP_TEAM_NT=${cfg%%:*} FFT_HIP_TEAM_ABLATE=${cfg##*:}
   for set in FETCH_SIZE WRITE_SIZE; do
-    timeout -k 10 300 rocprofv3 --pmc $set -d $O/c_${cfg/:/_}_$set --output-format csv -- python3 $R/bench.py --workload ${WL-1m} --steps 3 --warmup 1 --no-check --no-cpu-baseline > $O/c_${cfg/:/_}_$set.log 2>&1 || exit 1
+    timeout -k 10 300 rocprofv3 --pmc $set -d $O/c_${cfg/:/_}_$set --output-format csv -- python3 $R/bench.py --workload ${WL-1m} --steps 3 --warmup 1 --no-check --no-cpu-baseline --no-live-traffic > $O/c_${cfg/:/_}_$set.log 2>&1 || exit 1
   done
   timeout -k 10 300 python3 $R/bench.py --workload ${WL-1m} --steps 10 --warmup 2 --no-check --no-cpu-baseline > $O/c_${cfg/:/_}_bench.log 2>&1 || exit 1
 done
