@@ -284,7 +284,8 @@ __device__ __forceinline__ void fft_store16_pol(V16* ptr, const V16& v) {
     else if (POL == 5) asm volatile("global_store_dwordx4 %0, %1, off sc0 nt" ::"v"(ptr), "v"(raw) : "memory");
     else asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(ptr), "v"(raw) : "memory");
 }
-#define FFT_WAIT_VM_LE(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")  // at most n of my memory operations still in flight
+// at most n of my memory operations still in flight (the counter has 6 bits: a larger n is clamped, which only waits for more)
+#define FFT_WAIT_VM_LE(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((n) > 63 ? 63 : (n)) : "memory")
 #define FFT_WAVE_LOCKSTEP() ((void)0)
 // One 8-byte LDS access that STAYS one ds_read_b64 / ds_write_b64: hipcc otherwise fuses pairs of them into ds_read2_b64 /
 // ds_read2st64_b64 / ds_write2st64_b64, which move half the bytes per clock of the single forms and bank on 32 dwords in

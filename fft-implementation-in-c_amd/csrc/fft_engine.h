@@ -198,11 +198,17 @@ class Pow2Plan {
     const unsigned* run_if = nullptr;  // handed to the tile launches of the current execute (fallback mode)
     int team_pending = 0;        // team launches since the host last read the status word
     // what those launches were asked to do: replayed on the multi-pass schedule if one of them ends in TEAM_STATUS_TIMEOUT
-    // (recover_after_timeout).  An in-place execute cannot be replayed (a broken team has overwritten part of its input).
-    struct TeamExec { const cpx<T>* in; cpx<T>* out; int nb; bool inverse; bool scale_inverse; };
+    // (recover_after_timeout) -- where that is provably safe; see there.  `in` is what the replay reads: the caller's input, or the
+    // plan's staged copy of it for an in-place execute of a plan whose team kernel has not yet been seen to work (team_proven).
+    struct TeamExec { const cpx<T>* in; cpx<T>* out; int nb; bool inverse; bool scale_inverse; bool staged; };
     std::vector<TeamExec> team_log;
+    int team_log_dropped = 0;    // executes beyond the log's capacity since the last sync: lost if a timeout voids them
+    bool team_replay = true;     // the caller keeps every buffer of an execute alive and unmodified until the next sync (FFT_GPU_OPT_TEAM_NO_REPLAY clears it)
+    bool team_proven = false;    // a sync has seen a team launch of this plan end with status OK: in-place executes are no longer staged
+    cpx<T>* team_stage = nullptr;  // staged input of in-place executes until then (freed by the sync that proves the kernel)
+    size_t team_stage_bytes = 0, team_stage_used = 0;
     bool team_disabled = false;  // a team wait timed out once: the team kernel is never enabled again for this plan
-    int team_unrecoverable = 0;  // in-place executes among the ones a timeout invalidated (since the last recover_after_timeout)
+    int team_unrecoverable = 0;  // executes a timeout invalidated and recover_after_timeout could not repeat (since the last one)
     int team_fallbacks = 0;      // consecutive executes that ended in the two-pass fallback
     int team_last_status = -1;   // what the host last read from the status word (-1: never launched)
     bool team_force_fallback = false;  // test hook: the team kernel pretends its placement check failed
@@ -225,6 +231,9 @@ class Pow2Plan {
         if (team.tables) rt->dfree(team.tables);
         if (team.scratch) rt->dfree(team.scratch);
         if (team.sticky) rt->dfree(team.sticky);
+        if (team_stage) rt->dfree(team_stage);
+        team_stage = nullptr;
+        team_stage_bytes = team_stage_used = 0;
         team = TeamDesc<T>();
         tw_half = nullptr;
         scratch = nullptr;
@@ -1466,14 +1475,51 @@ class Pow2Plan {
             team_disabled = true;
             std::vector<TeamExec> log;
             log.swap(team_log);
-            for (const TeamExec& e : log) {
-                if ((const void*)e.in == (const void*)e.out) { lost++; continue; }
+            // A logged execute is repeated only where that is PROVABLY right (round-3 ADVICE): its input still holds what the caller put
+            // there.  Every launch since the last sync is suspect -- a broken team has written part of its output, and a launch fed by a
+            // suspect buffer has written garbage everywhere -- so an input is intact only if NO other logged execute wrote into it (a
+            // later one: the ping-pong A -> B, B -> A overwrites A before the replay reads it) unless that writer came EARLIER and has
+            // itself been repeated.  In place: only from the staged copy.  Executes beyond the log's capacity, and everything when the
+            // caller has not promised to keep its buffers until the sync (team_replay), are lost.
+            const size_t nbytes = (size_t)SZ << log2n;
+            auto overlap = [&](const void* a, size_t abytes, const void* b, size_t bbytes) {
+                const char *pa = (const char*)a, *pb = (const char*)b;
+                return pa < pb + bbytes && pb < pa + abytes;
+            };
+            std::vector<char> bad(log.size(), 0);  // the execute's output holds invalid data
+            for (size_t k = 0; k < log.size(); k++) {
+                const TeamExec& e = log[k];
+                const size_t bytes = nbytes * (size_t)e.nb;
+                bool ok = team_replay && team_log_dropped == 0 && !overlap(e.in, bytes, e.out, bytes);
+                for (size_t j = 0; ok && j < log.size(); j++) {
+                    if (j == k) continue;
+                    const size_t jb = nbytes * (size_t)log[j].nb;
+                    if (!overlap(e.in, bytes, log[j].out, jb)) continue;
+                    if (j > k || bad[j]) ok = false;  // written later, or by an execute that could not be repeated
+                }
+                // a staged copy is this execute's alone only if nothing was staged over it since
+                if (ok && e.staged && (k + 1 < log.size())) {
+                    for (size_t j = k + 1; ok && j < log.size(); j++)
+                        if (log[j].staged && overlap(e.in, bytes, log[j].in, nbytes * (size_t)log[j].nb)) ok = false;
+                }
+                if (!ok) { bad[k] = 1; lost++; continue; }
                 execute(e.in, e.out, e.nb, e.inverse, e.scale_inverse);
             }
+            lost += team_log_dropped;
             team_unrecoverable += lost;
         }
         team_log.clear();
+        team_log_dropped = 0;
+        team_stage_used = 0;
         return lost;
+    }
+    // a sync has read status OK for team launches of this plan: the teams form and their waits end on this device -- later
+    // in-place executes run without the staged copy
+    void team_seen_ok() {
+        team_proven = true;
+        if (team_stage) rt->dfree(team_stage);
+        team_stage = nullptr;
+        team_stage_bytes = team_stage_used = 0;
     }
 
     void execute(const cpx<T>* in, cpx<T>* out, int nb, bool inverse, bool scale_inverse = true) {
@@ -1520,9 +1566,31 @@ class Pow2Plan {
         run_if = nullptr;
         int mark0 = 0;
         if (team.ok && nb >= team.min_batch) {
-            launch_team(in, out, nb, inverse, scale);
+            // In place, and this plan's team kernel has never been seen to end well: run it from a copy of the input, so that a timeout
+            // (a member that never arrives: status 2) can be repaired like an out-of-place execute -- fft_gpu_execute has no failure
+            // mode (reference include/fft_gpu.h:102).  One device copy per such execute until the first sync proves the kernel; where
+            // the copy cannot be allocated the execute runs unstaged (and a timeout then reports it lost).
+            const cpx<T>* tin = in;
+            bool staged = false;
+            if ((const void*)in == (const void*)out && !team_proven && team_replay) {
+                const size_t bytes = ((size_t)SZ << log2n) * (size_t)nb;
+                if (team_stage_used + bytes > team_stage_bytes && team_stage_used == 0) {
+                    if (team_stage) rt->dfree(team_stage);
+                    team_stage = (cpx<T>*)rt->dmalloc(bytes);
+                    team_stage_bytes = team_stage ? bytes : 0;
+                }
+                if (team_stage && team_stage_used + bytes <= team_stage_bytes) {
+                    cpx<T>* dst = (cpx<T>*)((char*)team_stage + team_stage_used);
+                    rt->d2d_async(dst, in, bytes);
+                    team_stage_used += bytes;
+                    tin = dst;
+                    staged = true;
+                }
+            }
+            launch_team(tin, out, nb, inverse, scale);
             team_pending++;
-            if (team_log.size() < 4096) team_log.push_back(TeamExec{in, out, nb, inverse, scale_inverse});
+            if (team_log.size() < 4096) team_log.push_back(TeamExec{tin, out, nb, inverse, scale_inverse, staged});
+            else team_log_dropped++;
             rt->mark(0);
             run_if = team.ctl + fftk::TEAM_CTL_STATUS;
             mark0 = 1;

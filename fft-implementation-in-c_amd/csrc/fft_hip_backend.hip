@@ -123,6 +123,7 @@ struct HipRT {
     }
 
     void memset_async(void* p, int v, size_t bytes) { (void)hipMemsetAsync(p, v, bytes, stream); }
+    void d2d_async(void* dst, const void* src, size_t bytes) { (void)hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream); }
     // Team kernel (fft_team.h): one 512-thread workgroup per CU, 2^log2seats of them on each of n_xcc XCDs.  gfx950 has
     // 32 CUs per XCD in every partition mode (SPX 256 CUs = 8 XCDs, DPX 128 = 4, QPX 64 = 2, CPX 32 = 1), so the XCD
     // count follows from the device's CU count.  The kernel verifies the placement itself (HW_REG_XCC_ID, team_form);
@@ -259,7 +260,9 @@ const DeviceInfo* device_info(int dev) {
     }
     t.lds_limit = (int)lds;
     t.cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 1;
-    snprintf(t.name, sizeof(t.name), "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    // (prop.name is empty on hosts without the amdgpu.ids marketing-name table: say what is known instead of nothing)
+    snprintf(t.name, sizeof(t.name), "%s (%s, %d CUs)", prop.name[0] ? prop.name : (t.gfx950 ? "AMD Instinct MI355X-class GPU" : "AMD GPU"),
+             prop.gcnArchName, prop.multiProcessorCount);
     t.valid = true;
     d = t;
     return &d;
@@ -337,8 +340,9 @@ int team_status_of(Core* core) {
         const int lost = core->recover_after_timeout(true);
         if (hipStreamSynchronize(core->rt->stream) != hipSuccess) (void)hipGetLastError();
         if (lost)
-            fprintf(stderr, "fft_hip: a team kernel barrier timed out; %d in-place execute(s) since the last sync could not be repeated "
-                            "(their input is gone) and hold invalid data; this plan continues with the multi-pass schedule\n", lost);
+            fprintf(stderr, "fft_hip: a team kernel barrier timed out; %d execute(s) since the last sync could not be repeated (their input "
+                            "is gone, overwritten by a later execute, or not the caller's to keep) and hold invalid data; this plan continues "
+                            "with the multi-pass schedule\n", lost);
         else
             fprintf(stderr, "fft_hip: a team kernel barrier timed out; the executes since the last sync were repeated on the multi-pass "
                             "schedule, which this plan keeps from now on\n");
@@ -353,18 +357,51 @@ int team_status_of(Core* core) {
         }
     } else {
         core->team_fallbacks = 0;
+        if (st == fftk::TEAM_STATUS_OK && launches > 0) core->team_seen_ok();  // (in-place executes are no longer staged)
     }
-    if (st != fftk::TEAM_STATUS_TIMEOUT) core->team_log.clear();
+    if (st != fftk::TEAM_STATUS_TIMEOUT) {
+        core->team_log.clear();
+        core->team_log_dropped = 0;
+        core->team_stage_used = 0;
+    }
     return (int)st;
 }
 
+// every power-of-two core of a plan, whatever it is built of (Bluestein, 2D, real and fused plans run their transforms on cores of
+// their own: a team kernel's timeout there must reach fft_gpu_plan_sync like any other)
+template <class F>
+void for_each_core(fft_gpu_plan* p, F&& f) {
+    auto any = [&](auto* a) {
+        if (!a) return;
+        if (a->p2) f(a->p2);
+        if (a->bl) f(&a->bl->core);
+    };
+    if (p->p32) f(p->p32);
+    if (p->p64) f(p->p64);
+    if (p->b32) f(&p->b32->core);
+    if (p->b64) f(&p->b64->core);
+    auto two = [&](auto* d) {
+        if (!d) return;
+        any(&d->rowp);
+        if (d->colp) f(d->colp);
+        any(d->colt);
+    };
+    two(p->d32); two(p->d64);
+    if (p->r32) any(&p->r32->core);
+    if (p->r64) any(&p->r64->core);
+    if (p->f32) f(&p->f32->core);
+    if (p->f64) f(&p->f64->core);
+}
+
+// the worst of the plan's cores: TIMEOUT (2) > NO_TEAMS (1) > OK (0) > no team kernel / nothing launched (-1)
 int plan_team_status(fft_gpu_plan* p) {
     if (!p) return -1;
-    if (p->p32) return team_status_of(p->p32);
-    if (p->p64) return team_status_of(p->p64);
-    if (p->b32) return team_status_of(&p->b32->core);
-    if (p->b64) return team_status_of(&p->b64->core);
-    return -1;
+    int worst = -1;
+    for_each_core(p, [&](auto* c) {
+        const int st = team_status_of(c);
+        if (st > worst) worst = st;
+    });
+    return worst;
 }
 
 // bytes one execute reads from its input and writes to its output buffer
@@ -611,6 +648,7 @@ fft_gpu_plan_t fft_gpu_plan_1d_ex_hip(int n, int batch, fft_direction dir, fft_p
             ok = p->b64 && p->b64->build(&p->rt, n, p->dir, (int)algo, batch);
         }
     }
+    if (ok && !p->pow2) for_each_core(p, [](auto* c) { c->team_replay = false; });  // (a core of a composite plan transforms the plan's own intermediates)
     if (ok) ok = (hipStreamSynchronize(p->own_stream) == hipSuccess);
     if (!ok) {
         fprintf(stderr, "fft_hip: could not build a plan for n=%d batch=%d\n", n, batch);
@@ -675,6 +713,7 @@ static fft_gpu_plan* new_plan_shell(int n, int batch, int dir, fft_precision_t p
     return p;
 }
 static fft_gpu_plan_t finish_plan(fft_gpu_plan* p, bool ok, const char* what) {
+    if (ok) for_each_core(p, [](auto* c) { c->team_replay = false; });  // composite plans: a team timeout in a core is reported, never replayed
     if (ok) ok = (hipStreamSynchronize(p->own_stream) == hipSuccess);
     if (!ok) {
         fprintf(stderr, "fft_hip: could not build a %s plan\n", what);
@@ -957,13 +996,13 @@ int fft_gpu_plan_measure_hip(fft_gpu_plan_t p, int iters) {
 
 int fft_gpu_plan_set_option_hip(fft_gpu_plan_t p, fft_gpu_plan_option_t option, int value) {
     if (!p) return -1;
-    auto each_core = [&](auto&& f) {
-        if (p->p32) f(p->p32);
-        if (p->p64) f(p->p64);
-        if (p->b32) f(&p->b32->core);
-        if (p->b64) f(&p->b64->core);
-    };
+    auto each_core = [&](auto&& f) { for_each_core(p, f); };
     switch (option) {
+        case FFT_GPU_OPT_TEAM_NO_REPLAY:
+            // only plain 1D complex plans ever replay (the cores of composite plans transform the plan's own intermediates)
+            if (p->p32) p->p32->team_replay = value == 0;
+            if (p->p64) p->p64->team_replay = value == 0;
+            return 0;
         case FFT_GPU_OPT_TEAM_FORCE_FALLBACK:
             each_core([&](auto* c) { c->team_force_fallback = value != 0; });
             return 0;

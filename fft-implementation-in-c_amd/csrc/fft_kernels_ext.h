@@ -193,8 +193,13 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS(512) copy_dma_kernel(const vec16<float>* in, v
     };
     if (t < n_tiles) dma(t, 0);
     int im = 0;
+    bool first = true;
     for (; t < n_tiles; t += FFT_NBLOCKS, im ^= 1) {
-        FFT_WAIT_VM_LE(8);  // everything but my 8 stores of the previous tile: this tile has landed
+        // this tile has landed: behind its 8 pieces this thread has issued the 8 stores of the previous tile -- except on the first
+        // tile, where the pieces are the youngest thing in flight (vmcnt(8) passed at once there and the reads ran early)
+        if (first) FFT_WAIT_VM0();
+        else FFT_WAIT_VM_LE(8);
+        first = false;
         FFT_SYNC_LDS();
         if (t + FFT_NBLOCKS < n_tiles) dma(t + FFT_NBLOCKS, im ^ 1);
         const vec16<float>* img = reinterpret_cast<const vec16<float>*>(smem + im * 65536);

@@ -293,7 +293,7 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
 
     int n_ev = 0;
     auto ev = [&]() __attribute__((always_inline)) {
-        if (p.trace && tid == 0 && n_ev < p.trace_events - 1) {
+        if (p.trace && tid == 0 && n_ev < p.trace_events - 2) {  // (the last two slots: kernel-entry clock, team / seat)
             p.trace[(long long)FFT_BID * p.trace_events + n_ev] = FFT_CLOCK();
             n_ev++;
         }

@@ -31,6 +31,10 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
     X(double, 8, 3, 1, 8, 6, 0, 1)   /* fp64 n = 2^14: 256 x 64, one CU per transform */                               \
     X(double, 8, 3, 2, 8, 7, 1, 1)   /* fp64 n = 2^15: 256 x 128, teams of 2 */                                        \
     X(double, 8, 3, 3, 8, 8, 2, 1)   /* fp64 n = 2^16: 256 x 256, teams of 4 */
+// Measured and NOT instantiated (round 4, profiles/r4_ab_fp64_quad_e16.txt): fp64 n = 2^17 ... 2^19 with 16 values per thread and chunk on
+// 256-thread workgroups (one wave per SIMD, 512 registers per wave: <double, 16, 4, 3, 10, 9, 5, 2>, <double, 16, 3, 3, 9, 9, 4, 1 / 2>,
+// <double, 16, 3, 2, 9, 8, 3, 1>).  Correct (parity-green on the device), but 41 - 73 registers still spill and one wave per SIMD hides no
+// latency: 75 / 75 / 84 Gpoint/s against 88 - 91 / 97 - 101 / 103 - 107 of round 2's team_defer_kernel, which keeps those sizes.
 #define FFT_QUAD_EXTERN(T, ...) extern template __global__ void team_quad_kernel<T, __VA_ARGS__>(TeamParams<T>);
 FFT_QUAD_INSTANCES(FFT_QUAD_EXTERN)
 #undef FFT_QUAD_EXTERN

@@ -111,20 +111,31 @@ _plans = {}
 
 
 def engine_local_fft(t, direction):
-    """Batched transform of a contiguous CUDA tensor [batch, n] through the C ABI (plans cached per shape / direction)."""
+    """Batched transform of a contiguous CUDA tensor [batch, n] through the C ABI (plans cached per shape / direction / stream)."""
     import fftlib
     assert t.is_cuda and t.is_contiguous()
     batch, n = t.shape
     dt = np.complex64 if t.dtype == torch.complex64 else np.complex128
-    key = (n, batch, direction, dt, t.device.index)
+    # torch's CURRENT stream of that device.  Handle 0 -- torch's default stream -- would mean "the plan's own stream" to the C ABI:
+    # name the legacy default stream explicitly (hipStreamLegacy = 1), or the transform would race with torch's kernels around it
+    stream = torch.cuda.current_stream(t.device).cuda_stream or fftlib.HIP_STREAM_LEGACY
+    # one plan per STREAM as well: a plan owns one set of scratch buffers, exchange windows and control words, so two torch streams
+    # running the same shape at once must not share it (ADVICE r3)
+    key = (n, batch, direction, dt, t.device.index, stream)
     with torch.cuda.device(t.device):  # the plan lives on the TENSOR's device, not on whatever device is current (ADVICE r2)
+        prev = fftlib.get_device()  # the library's current device is global state of its own: put it back (ADVICE r3)
         fftlib.set_device(t.device.index)
-        if key not in _plans:
-            _plans[key] = fftlib.Plan(n, batch, direction, dt)
-        # every call: torch's CURRENT stream of that device (a later call may run under another stream).  Handle 0 -- torch's
-        # default stream -- would mean "the plan's own stream" to the C ABI: name the legacy default stream explicitly
-        # (hipStreamLegacy = 1), or the transform would race with torch's kernels around it
-        _plans[key].set_stream(torch.cuda.current_stream(t.device).cuda_stream or fftlib.HIP_STREAM_LEGACY)
-        out = torch.empty_like(t)
-        _plans[key].execute_ptr(t.data_ptr(), out.data_ptr())
+        try:
+            if key not in _plans:
+                plan = fftlib.Plan(n, batch, direction, dt)
+                plan.set_stream(stream)
+                # torch's caching allocator may hand `t` / `out` to somebody else as soon as the stream-ordered work is queued: the
+                # library must never repeat an execute from these pointers after a team-kernel timeout (include/fft_hip.h)
+                plan.set_option(fftlib.OPT_TEAM_NO_REPLAY, 1)
+                _plans[key] = plan
+            out = torch.empty_like(t)
+            _plans[key].execute_ptr(t.data_ptr(), out.data_ptr())
+        finally:
+            if prev >= 0 and prev != t.device.index:
+                fftlib.set_device(prev)
     return out

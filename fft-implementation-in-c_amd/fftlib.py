@@ -136,13 +136,18 @@ def init():
 
 
 EXP_LIB_PATH = os.path.join(HERE, "libfft_mi355x_exp.so")  # -DFFT_EXPERIMENTS build: kernel-variant switches, ablation bits
-OPT_TEAM_FORCE_FALLBACK, OPT_TEAM_ENABLE, OPT_NO_FUSION, OPT_NO_CHAIN = 1, 2, 3, 4
+OPT_TEAM_FORCE_FALLBACK, OPT_TEAM_ENABLE, OPT_NO_FUSION, OPT_NO_CHAIN, OPT_TEAM_NO_REPLAY = 1, 2, 3, 4, 5
 
 
 def set_device(index):
     """Make `index` the device new plans and buffers live on (fft_gpu_set_device; an 8-GPU process sets each in turn)."""
     if load().fft_gpu_set_device(int(index)) != 0:
         raise RuntimeError("fft_gpu_set_device(%d) failed" % index)
+
+
+def get_device():
+    """The device new plans and buffers currently live on (fft_gpu_get_device_hip)."""
+    return load().fft_gpu_get_device_hip()
 
 
 def set_policy(team=-1, min_batch=-1, chunk_mb=-1):

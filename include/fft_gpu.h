@@ -55,7 +55,8 @@ void fft_gpu_destroy_plan(fft_gpu_plan_t plan); /* NULL-safe */
 int fft_gpu_dft_1d(complex_t* in, complex_t* out, int n, fft_direction direction);
 int fft_gpu_dft_1d_batch(complex_t* in, complex_t* out, int n, int batch, fft_direction direction);
 
-/* 2D: stubs exactly like the reference (fft_gpu.c:377-394): NULL / -1 */
+/* 2D complex transforms of one row-major rows x cols matrix (stubs in the reference, gpu/fft_gpu.c:377-394: NULL / -1; real here: rows as
+ * one batched 1D execute, columns as the engine's strided column pass, the inverse scaled once by 1 / (rows * cols) -- DESIGN.md 4.5) */
 fft_gpu_plan_t fft_gpu_plan_2d(int rows, int cols, fft_direction direction);
 int fft_gpu_dft_2d(complex_t* in, complex_t* out, int rows, int cols, fft_direction direction);
 

@@ -101,9 +101,12 @@ typedef enum {
     FFT_GPU_OPT_TEAM_ENABLE = 2,         /* 0: run the multi-pass schedule only; 1: back to the team kernel where the plan has one */
     FFT_GPU_OPT_NO_FUSION = 3,           /* 1: Bluestein / fused-consumer plans run their element-wise steps as kernels of their own
                                             instead of fusing them into the FFT passes (same results to rounding; tests) */
-    FFT_GPU_OPT_NO_CHAIN = 4             /* 1: Bluestein / fused-consumer plans keep the forward transform's last pass and the inverse
+    FFT_GPU_OPT_NO_CHAIN = 4,            /* 1: Bluestein / fused-consumer plans keep the forward transform's last pass and the inverse
                                             transform's first pass as two kernels (by default they run as one where their tiles agree
                                             and the transform has >= 2^19 points; tests); 2: as one wherever the tiles agree (tools) */
+    FFT_GPU_OPT_TEAM_NO_REPLAY = 5       /* 1: the caller does NOT keep the buffers of its asynchronous executes alive and unmodified until
+                                            the next fft_gpu_plan_sync_hip (e.g. they come from a stream-ordered caching allocator): a team
+                                            kernel timeout is then never repaired by repeating executes, fft_gpu_plan_sync_hip returns -1 */
 } fft_gpu_plan_option_t;
 
 /* Fused consumers of the transform (reference applications/convolution.c, applications/power_spectrum.c): FFT ->
@@ -163,10 +166,16 @@ int fft_gpu_plan_set_stream_hip(fft_gpu_plan_t plan, void* hip_stream);
 int fft_gpu_execute_ptr_hip(fft_gpu_plan_t plan, const void* d_in, void* d_out); /* async on the plan's stream */
 /* Waits for the plan's stream.  0: every execute since the last sync holds valid results.  Should a team kernel's bounded wait
  * have run out (a member of a formed team stopped making progress: a hardware fault, not load -- formation under load falls back
- * BEFORE anything is touched), the team kernel is retired for this plan and every OUT-OF-PLACE execute since the last sync is
- * repeated on the multi-pass schedule before this returns (still 0).  -1: the stream failed, or such a timeout hit an IN-PLACE
- * execute -- its input is partly overwritten, the data is invalid and stderr says so.  (fft_gpu_execute() of fft_gpu.h is void, as in
- * the reference: gpu/fft_cuda.cu:166-185; callers that need the status of in-place team executes sync through this function.) */
+ * BEFORE anything is touched), the team kernel is retired for this plan and the executes since the last sync are repeated on the
+ * multi-pass schedule before this returns (still 0) -- WHERE THAT IS PROVABLY RIGHT: the plan is a plain 1D complex plan, and the
+ * execute's input still holds the caller's data, i.e. it is out of place and no LATER execute since the last sync wrote into its
+ * input (A -> B then B -> A: the second launch has overwritten A), or it is in place and ran from the plan's staged copy (the plan
+ * stages the input of in-place executes until one sync has seen its team kernel end well, so the FIRST use of a plan on a device is
+ * always repairable).  Contract for asynchronous callers: every buffer handed to fft_gpu_execute_ptr_hip stays allocated and
+ * unmodified until the next sync (or set FFT_GPU_OPT_TEAM_NO_REPLAY).  -1: the stream failed, or a timeout hit an execute that
+ * could not be repeated (stderr says how many): that data is invalid.  Bluestein, 2D, real and fused plans never repeat (their
+ * cores transform the plan's own intermediates): a timeout in one of their cores is reported as -1.  (fft_gpu_execute() of
+ * fft_gpu.h is void, as in the reference: gpu/fft_cuda.cu:166-185, and blocks: its buffers are the caller's for the duration.) */
 int fft_gpu_plan_sync_hip(fft_gpu_plan_t plan);
 int fft_gpu_plan_set_option_hip(fft_gpu_plan_t plan, fft_gpu_plan_option_t option, int value);
 /* planner policy for plans created after the call; a negative argument keeps the current value.  team_mode: 0 never

@@ -127,6 +127,9 @@ static int run(const void* in, void* out, int n, int batch, int dir, int algo, i
             if (plan.wide.ok) info[6] |= 16;  // wide_row_kernel (fft_wide_row.h) runs the plain executes
         }
         plan.execute((const C*)in, (C*)out, batch, dir > 0);
+        // FFT_EMU_PINGPONG: a second execute back into the first one's input before the "sync" (A -> B, then B -> A): after a timeout
+        // neither can be repeated -- A was overwritten by the later launch, B was written by a launch that is void
+        if (getenv("FFT_EMU_PINGPONG") && in != out) plan.execute((const C*)out, (C*)in, batch, dir > 0);
         if (plan.team.ctl && getenv("FFT_EMU_RECOVER")) {
             // what the HIP backend does when it synchronizes (team_status_of): a timed-out team kernel's executes are
             // replayed on the multi-pass schedule; info[3] = executes that could not be (in place)

@@ -37,6 +37,7 @@ struct Runtime {
     int num_cus() { return cus; }
     void mark(int) {}
     void memset_async(void* p, int v, size_t bytes) { memset(p, v, bytes); }
+    void d2d_async(void* dst, const void* src, size_t bytes) { memcpy(dst, src, bytes); }
     // team kernel geometry for the emulation (0 = no team kernel): bits 0-3 log2(seats per "XCD") + 1, 4-7 "XCDs",
     // 8-19 threads, bit 20: pretend the placement is wrong (one "XCD" gets a workgroup too many) to exercise the fallback
     int team_mode = 0;

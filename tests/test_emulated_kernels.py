@@ -255,7 +255,10 @@ def test_team_kernel_timeout_is_repaired_on_the_multi_pass_schedule(quad, monkey
     """VERDICT r2 item 6.  A member of a formed team never arrives (FFT_EMU_DROP_BLOCK leaves right after formation): the team's
     waits run into their bound, the kernel reports TIMEOUT and ends.  What the host does next (HIP: team_status_of inside
     fft_gpu_plan_sync; here FFT_EMU_RECOVER): the out-of-place execute is REPEATED on the multi-pass schedule and the result is
-    correct; an in-place execute cannot be repeated (its input is partly overwritten) and is reported as lost."""
+    correct.  Round 4: an IN-PLACE execute of a plan whose team kernel has not yet been seen to end well
+    runs from a staged copy of its input and is repeated from that copy (fft_gpu_execute has no failure mode, reference
+    include/fft_gpu.h:102); a ping-pong A -> B, B -> A between two syncs is NOT repeated (the later launch has overwritten A, and B was
+    written by a void launch): both executes are reported lost instead of being "repaired" from garbage."""
     monkeypatch.setenv("FFT_EMU_DROP_BLOCK", "1")
     monkeypatch.setenv("FFT_EMU_TEAM_TIMEOUT_MS", "300")
     monkeypatch.setenv("FFT_EMU_RECOVER", "1")
@@ -270,7 +273,11 @@ def test_team_kernel_timeout_is_repaired_on_the_multi_pass_schedule(quad, monkey
     assert info[3] == 1100, "timeout seen, nothing lost: %d" % info[3]
     assert rel(y, oracle(x, -1)) < TEAM_TOL[np.complex64]
     y, info = E.emu_fft_team(x, -1, inplace=True, **geo)
-    assert info[3] == 1101, "timeout seen, the in-place execute is reported as lost: %d" % info[3]
+    assert info[3] == 1100, "timeout seen, the in-place execute repeated from its staged input: %d" % info[3]
+    assert rel(y, oracle(x, -1)) < TEAM_TOL[np.complex64]
+    monkeypatch.setenv("FFT_EMU_PINGPONG", "1")
+    y, info = E.emu_fft_team(x, -1, **geo)
+    assert info[3] == 1102, "timeout seen, neither execute of the ping-pong may be repeated: %d" % info[3]
 
 
 def test_team_quad_kernel_falls_back_when_teams_cannot_form(monkeypatch):

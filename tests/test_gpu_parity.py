@@ -543,6 +543,32 @@ def test_full_size_config4_shard_and_config5(gpu_lib):
 # plans it for every size it is built for and any batch (the default policy only uses it where it measured faster and
 # from 2 GiB per execute up), so that all ten instantiations are parity-checked on the device.
 # ---------------------------------------------------------------------------
+def test_first_in_place_team_execute_runs_from_a_staged_copy(gpu_lib):
+    """Round-3 review item 6: the FIRST in-place execute of a plan (its team kernel not yet seen to end well on this device) reads a
+    staged copy of its input, so that a team-kernel timeout could be repaired like an out-of-place one; once a sync has seen status 0
+    the staging stops.  Both executes must give the same, correct spectrum, and the second must not be slower for a copy."""
+    import fftlib
+    fftlib.set_policy(team=2)
+    n, batch = 1 << 18, 64
+    x = lcg(n, batch, np.complex64, seed=5)
+    ref = np.fft.fft(x.astype(np.complex128), axis=1)
+    buf = fftlib.DeviceBuffer(x.nbytes)
+    plan = fftlib.Plan(n, batch, -1, np.complex64)
+    assert plan.info().team_kernel == 3
+    buf.upload(x)
+    plan.execute_ptr(buf.ptr, buf.ptr)  # staged
+    assert plan.team_status() == 0
+    y1 = buf.download(x.shape, np.complex64)
+    assert rel(y1, ref) <= 2e-6
+    buf.upload(x)
+    plan.execute_ptr(buf.ptr, buf.ptr)  # proven: unstaged
+    assert plan.team_status() == 0
+    assert np.array_equal(buf.download(x.shape, np.complex64), y1)
+    plan.set_option(fftlib.OPT_TEAM_NO_REPLAY, 1)  # (accepted by plain 1D plans)
+    plan.destroy()
+    buf.free()
+
+
 def _team_plan(monkeypatch, n, batch, direction, dtype, mode="2"):
     import fftlib
     fftlib.set_policy(team=int(mode))  # tests/conftest.py puts the default policy back after every test
@@ -566,6 +592,8 @@ def test_team_kernel_vs_oracle(gpu_lib, monkeypatch, log2n, dtype):
     for d in (-1, 1):
         plan = _team_plan(monkeypatch, n, batch, d, dtype)
         assert plan.info().team_tiles == tiles
+        # team_quad_kernel at every built size but fp64 2^17 ... 2^19, which keep round 2's team_defer_kernel (fft_team_quad_decl.h)
+        assert plan.info().team_kernel == (2 if (dtype == np.complex128 and log2n >= 17) else 3)
         buf.upload(x)
         out.upload(np.full_like(x, np.nan))
         plan.execute_ptr(buf.ptr, out.ptr)
