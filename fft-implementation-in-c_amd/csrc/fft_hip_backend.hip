@@ -905,14 +905,25 @@ double fft_gpu_stream_bench_hip(size_t bytes, int iters, int mode) {
     const fftk::vec16<float>* in = (const fftk::vec16<float>*)a;
     fftk::vec16<float>* out = (fftk::vec16<float>*)b;
     double best = -1.0;
-    const int n_shapes = mode == 0 ? 13 : 12;
+    // shapes 0 - 11: grid-stride (1 / 4 / 8 accesses in flight x 8 / 16 workgroups per CU x plain / nt); 12 (copy only): the LDS-DMA tile
+    // copy; 13 - 18: tile-wise streams in the single-pass FFT kernels' shape, 4 / 6 / 8 workgroups per CU x plain / nt
+    const int n_shapes = 19;
     for (int shape = 0; shape < n_shapes; shape++) {
-        const int per_cu = (shape / 3) % 2 ? 16 : 8;  // resident 256-thread workgroups per CU
-        const bool nt = shape >= 6;
+        if (shape == 12 && mode != 0) continue;
+        const int per_cu = shape >= 13 ? (4 + 2 * ((shape - 13) % 3)) : (shape / 3) % 2 ? 16 : 8;  // resident 256-thread workgroups per CU
+        const bool nt = shape >= 13 ? shape >= 16 : shape >= 6;
         const unsigned grid = (unsigned)(cus * per_cu);
         for (int rep = 0; rep < 2; rep++) {
             (void)hipEventRecord(e0, nullptr);
             for (int it = 0; it < iters; it++) {
+                if (shape >= 13) {
+                    const long long n_tiles = (long long)(bytes / 32768);
+#define FFT_TILE_LAUNCH(M) do { if (nt) hipLaunchKernelGGL((fftk::stream_tile_kernel<M, 1>), dim3(grid), dim3(256), 0, nullptr, in, out, n_tiles); \
+                                else hipLaunchKernelGGL((fftk::stream_tile_kernel<M, 0>), dim3(grid), dim3(256), 0, nullptr, in, out, n_tiles); } while (0)
+                    if (mode == 0) FFT_TILE_LAUNCH(0); else if (mode == 1) FFT_TILE_LAUNCH(1); else FFT_TILE_LAUNCH(2);
+#undef FFT_TILE_LAUNCH
+                    continue;
+                }
                 if (shape == 12) {
                     const void* key = reinterpret_cast<const void*>(fftk::copy_dma_kernel);
                     (void)hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
