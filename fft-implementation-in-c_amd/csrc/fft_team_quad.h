@@ -79,9 +79,9 @@ FFT_DEVICE void quad_st(cpx<T>* p, cpx<T> v) {
 #ifndef QUAD_EARLY_CHUNK1  // 1: chunk 1 of the team's next transform is requested in round 3 too (behind the round's last image reads), not at chunk 0's barrier
 #define QUAD_EARLY_CHUNK1 1
 #endif
-#ifndef QUAD_DEFER_STORES  // 1: a transform's result stores go out in four parts from the column step of the team's NEXT transform (see `final_part`).
-#define QUAD_DEFER_STORES 0  // Measured (profiles/r4_ab_defer_stores.txt, r4_ab_store_split.txt, r4_ab_defer_late.txt): +1.3 % at n = 2^20, +-0 below: off
-#endif
+#ifndef QUAD_DEFER_STORES  // 1: a transform's result stores go out in four parts from the column step of the team's NEXT transform (see `final_part`);
+#define QUAD_DEFER_STORES -1  // 2 / 3: each part by a quarter / a half of the waves at a time; 0: all of them when the last round is over; -1: 1 for teams of
+#endif                        // 32 (n = 2^20: +1.3 ... 2 % in four same-box A/Bs), 0 below (+-1 %).  profiles/r4_ab_defer_*.txt
 #ifndef QUAD_ABL  // timing experiments only (tools/ab_quad.sh variants; results invalid): 1 no result stores, 2 no stage barrier in the column
 #define QUAD_ABL 0  // step, 4 none in the row step, 8 no column-step arithmetic, 16 no window stores, 32 no row-step arithmetic
 #endif
@@ -238,6 +238,7 @@ FFT_DEVICE void quad_twiddle_kb(cpx<T> (&x)[E], const cpx<T> (&v)[E], const cpx<
 template <typename T, int E, int LOG2RA, int LOG2RB, int LOG2L1, int LOG2L2, int LOG2TS, int SLOTS>
 FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamParams<T> p) {
     constexpr bool QUAD_ONE_SLOT = SLOTS == 1;
+    constexpr int DEFER = QUAD_DEFER_STORES >= 0 ? QUAD_DEFER_STORES : ((LOG2TS >= 5 && sizeof(T) == 4) ? 1 : 0);
     static_assert(SLOTS == 1 || SLOTS == 2, "one or two window slots");
     constexpr int V = vec16<T>::V;  // values per 16-byte access: 2 (fp32: the values of two adjacent rows travel together), 1 (fp64)
     using S = QuadShape<E, LOG2RA, LOG2RB, LOG2L1, LOG2L2, LOG2TS>;
@@ -257,7 +258,9 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
 
     const int tid0 = FFT_TID;
     const int tid = tid0;
-    unsigned char* const img_b[2] = {smem, smem + IMG};
+    // (a function, not an array of two pointers: an array indexed by a loop variable that the unroller leaves alone -- it does when the loop
+    // body grows -- is promoted to a constant global, whose initializer, an LDS address, the backend cannot express)
+    auto img_b = [&](int i) __attribute__((always_inline)) -> unsigned char* { return smem + (size_t)i * IMG; };
     unsigned char* const tab_bytes = smem + 2 * (size_t)IMG;
     const unsigned img_lds0 = FFT_LDS_ADDR(smem);
     {
@@ -371,10 +374,10 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
         const unsigned lds = img_lds0 + (unsigned)im * IMG;
         if (p.nt_mask & 1) {
             FFT_UNROLL
-            for (int i = 0; i < NCH; i++) FFT_DMA16_NT(src + i * step, img_b[im], lds, (unsigned)(i * NTHR + tid) * 16u);
+            for (int i = 0; i < NCH; i++) FFT_DMA16_NT(src + i * step, img_b(im), lds, (unsigned)(i * NTHR + tid) * 16u);
         } else {
             FFT_UNROLL
-            for (int i = 0; i < NCH; i++) FFT_DMA16(src + i * step, img_b[im], lds, (unsigned)(i * NTHR + tid) * 16u);
+            for (int i = 0; i < NCH; i++) FFT_DMA16(src + i * step, img_b(im), lds, (unsigned)(i * NTHR + tid) * 16u);
         }
     };
     // LDS-DMA of my image of window slot `slot` (IMG contiguous bytes, served by the XCD's L2)
@@ -385,10 +388,10 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
         const unsigned lds = img_lds0 + (unsigned)im * IMG;
         if (p.nt_mask & 4) {
             FFT_UNROLL
-            for (int i = 0; i < NCH; i++) FFT_DMA16_L2_NT(src + (size_t)i * NTHR * 16, img_b[im], lds, (unsigned)(i * NTHR + tid) * 16u);
+            for (int i = 0; i < NCH; i++) FFT_DMA16_L2_NT(src + (size_t)i * NTHR * 16, img_b(im), lds, (unsigned)(i * NTHR + tid) * 16u);
         } else {
             FFT_UNROLL
-            for (int i = 0; i < NCH; i++) FFT_DMA16_L2(src + (size_t)i * NTHR * 16, img_b[im], lds, (unsigned)(i * NTHR + tid) * 16u);
+            for (int i = 0; i < NCH; i++) FFT_DMA16_L2(src + (size_t)i * NTHR * 16, img_b(im), lds, (unsigned)(i * NTHR + tid) * 16u);
         }
     };
 
@@ -462,7 +465,7 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
             }
         }
     };
-    cpx<T>* out_prev = nullptr;  // QUAD_DEFER_STORES: where the results still in zt belong
+    cpx<T>* out_prev = nullptr;  // DEFER: where the results still in zt belong
 
     long long cur = team;  // the transform in hand
     dma_chunk(p.in + cur * n, 0, 0);
@@ -491,7 +494,7 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
             // my pieces of the chunk have landed ... everybody's have; the other image was last read before this barrier.
             // What may still be in flight behind chunk 0's DMA are the previous transform's 4 E / 2 result stores (vmcnt counts
             // in issue order)
-            if (QUAD_DEFER_STORES) {
+            if (DEFER) {
                 // (chunk a's pieces are the youngest thing this thread has issued: its request follows part a - 1's stores -- that order measured
                 // faster than the request first --, so the wait for the pieces is a wait for everything)
                 FFT_WAIT_VM0();
@@ -501,13 +504,24 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
             }
             FFT_SYNC_LDS();
             ev();
-            if (QUAD_DEFER_STORES && it > 0) final_part(a, out_prev);  // the previous transform's results, part a
+            // the previous transform's results, part a.  QUAD_DEFER_STORES = 2: not by every wave at once -- a quarter of the waves at each of
+            // four points of the chunk (here, behind stage 1's butterflies, behind the stage barrier, under stage 2's reads): the waves that
+            // sit in the store queue are then never the SIMD partners... of ALL the waves that could compute meanwhile
+            // (= 3: two halves, here and behind the stage barrier)
+            const int sgrp = DEFER == 3 ? 2 * ((tid0 * 2) / NTHR) : (tid0 * 4) / NTHR;  // wave-uniform: NTHR / 4 is a multiple of the wave size on the device
+            const bool drain = DEFER && it > 0;
+            if (drain && (DEFER == 1 || sgrp == 0)) final_part(a, out_prev);
+            int n_mark = 0;
+            auto store_mark = [&](int) __attribute__((always_inline)) {
+                if (DEFER == 2 && drain && sgrp == 1 && n_mark == 1) final_part(a, out_prev);
+                n_mark++;
+            };
             // the claim for the transform after this one (used at the combine: its latency is hidden).  Issued HERE, behind the wait that
             // counts the previous transform's result stores (vmcnt counts in issue order: in front of it the claim would make its wave
             // wait for the first of those stores, and the team for that wave: -10 % at n = 2^20)
             if (a == 3 && p.dynamic && s == 0 && tid == 0) claimed = FFT_ATOMIC_ADD_AGENT_RELAXED(claim, 1u) + (unsigned)n_teams;
             if (a + 1 < 4 && !(QUAD_EARLY_CHUNK1 && a == 0 && it > 0)) dma_chunk(inb, a + 1, (a + 1) & 1);
-            cpx<T>* img = reinterpret_cast<cpx<T>*>(img_b[a & 1]);
+            cpx<T>* img = reinterpret_cast<cpx<T>*>(img_b(a & 1));
             int t = tid0;
             FFT_OPAQUE(t);
             cpx<T> v[E];
@@ -534,12 +548,14 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
             quad_stage2_dft<T, E, RA>(v);
             fine(0);  // 7: dft
 #else
-            if (!(QUAD_ABL & 8) || p.nb < 0) quad_stage1<T, E, RA, LOG2NC, LOG2L1, true>(img, wlA, t & (NC - 1), t >> LOG2NC, p.inverse != 0);
+            if (!(QUAD_ABL & 8) || p.nb < 0) quad_stage1<T, E, RA, LOG2NC, LOG2L1, true>(img, wlA, t & (NC - 1), t >> LOG2NC, p.inverse != 0, store_mark);
             if (!(QUAD_ABL & 2) || p.nb < 0) FFT_SYNC_LDS();
+            if (DEFER >= 2 && drain && sgrp == 2) final_part(a, out_prev);
             FFT_OPAQUE(t);
             const int g = t & (RA - 1), c2 = ap + 4 * sender_cc(t);
             if (!(QUAD_ABL & 8) || p.nb < 0) {
                 quad_stage2_read<T, E, LOG2NC>(v, img, quad_rot<RA, NC>(c2, g), g);
+                if (DEFER == 2 && drain && sgrp == 3) final_part(a, out_prev);
                 quad_stage2_dft<T, E, RA>(v);
             } else {
                 FFT_UNROLL
@@ -673,7 +689,7 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
                 wait_all(G + 2 * r + 2, r == 2);  // the team's
                 send(r + 1);
             }
-            cpx<T>* img = reinterpret_cast<cpx<T>*>(img_b[r & 1]);
+            cpx<T>* img = reinterpret_cast<cpx<T>*>(img_b(r & 1));
             int t = tid0;
             FFT_OPAQUE(t);
             quad_stage1<T, E, RB, LOG2NR, LOG2L2, false>(img, wlB, t & (NR - 1), t >> LOG2NR, false);
@@ -719,7 +735,7 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
                 learn_next();
                 if (nxt < p.nb) dma_chunk(p.in + nxt * n, 0, 0);  // image 0 was last read in round 2
             }
-            cpx<T>* img = reinterpret_cast<cpx<T>*>(img_b[r & 1]);
+            cpx<T>* img = reinterpret_cast<cpx<T>*>(img_b(r & 1));
             int t = tid0;
             FFT_OPAQUE(t);
             if (!(QUAD_ABL & 32) || p.nb < 0) quad_stage1<T, E, RB, LOG2NR, LOG2L2, false>(img, wlB, t & (NR - 1), t >> LOG2NR, false);
@@ -760,7 +776,7 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
         }
         // ---- final radix-4 over the rounds and the result stores: now (QUAD_DEFER_STORES = 0) or from the next transform's column step
         ev();
-        if (QUAD_DEFER_STORES) {
+        if (DEFER) {
             out_prev = outb;
         } else {
             FFT_UNROLL
@@ -769,7 +785,7 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
         ev();
         cur = nxt;
     }
-    if (QUAD_DEFER_STORES && out_prev) {  // the team's last transform
+    if (DEFER && out_prev) {  // the team's last transform
         FFT_LDS_FRESH();
         if (!sh[3]) {
             FFT_UNROLL

@@ -2,6 +2,8 @@
 workgroup = host threads (tests/emu), checked against the oracle.  This validates the index algebra (Stockham
 digit order, four-step strides, LDS layouts, persistent tile walk + prefetch) in a container without a GPU.
 It is NOT a product path: the shipped library has no CPU implementation."""
+import os
+
 import numpy as np
 import pytest
 
@@ -231,6 +233,37 @@ def test_team_quad_kernel(n, batch, log2seats, n_xcc, threads, lds, dtype, monke
             assert info[0] // 100 == 4 and info[6] & 8, "team_quad_kernel was not planned"
             assert info[5] == 1, "status / fallback / timeout counters: %d" % info[5]
             assert rel(y, oracle(x, d)) < TEAM_TOL[dtype], (n, batch, d, inplace)
+
+
+def test_team_quad_kernel_with_deferred_result_stores(tmp_path):
+    """Round 4: on teams of 32 (the device's n = 2^20) a transform's result stores go out in four parts from the column step of the team's NEXT
+    transform (QUAD_DEFER_STORES; loop-carried results, the last transform's in an epilogue, dynamic claims, in place).  The emulated shapes
+    have small teams, where the schedule is off by default: this test builds the emulation with the schedule forced on and runs the quad cases
+    in a process of its own (the library is chosen when it is first loaded)."""
+    import subprocess
+    import sys
+    so = str(tmp_path / "libfft_emu_defer.so")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-DFFT_EMU", "-DFFT_EXPERIMENTS", "-DQUAD_DEFER_STORES=1", "-fPIC", "-shared", "-pthread",
+                    "-I" + E.CSRC, os.path.join(E.EMU_DIR, "emu_fft.cpp"), "-o", so], check=True)
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "import emu_lib as E, oracle_lib as O\n"
+        "import os; os.environ['FFT_EMU_TEAM_QUAD'] = '1'\n"
+        "for n, batch, log2seats, n_xcc, threads, lds in %r:\n"
+        "    x = O.gen_lcg(n, 23, batch).astype(np.complex64)\n"
+        "    ref = np.fft.fft(x.astype(np.complex128), axis=1)\n"
+        "    for dyn in ('0', '1'):\n"
+        "        os.environ['FFT_HIP_TEAM_DYNAMIC'] = dyn\n"
+        "        for inplace in (False, True):\n"
+        "            y, info = E.emu_fft_team(x, -1, log2seats=log2seats, n_xcc=n_xcc, threads=threads, lds_budget=lds, inplace=inplace)\n"
+        "            assert info[6] & 8 and info[5] == 1, (n, info[5])\n"
+        "            err = np.linalg.norm(y - ref) / np.linalg.norm(ref)\n"
+        "            assert err < 2e-6, (n, batch, dyn, inplace, err)\n"
+        "print('ok')\n" % (os.path.dirname(os.path.abspath(__file__)), QUAD_CASES))
+    env = dict(os.environ, FFT_EMU_SO=so)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
 
 
 def test_team_quad_kernel_static_and_dynamic_split_of_the_batch(monkeypatch):
