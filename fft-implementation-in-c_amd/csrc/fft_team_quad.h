@@ -83,7 +83,7 @@ FFT_DEVICE void quad_st(cpx<T>* p, cpx<T> v) {
 #define QUAD_DEFER_STORES -1  // 2 / 3: each part by a quarter / a half of the waves at a time; 0: all of them when the last round is over; -1: 1 for teams of
 #endif                        // 32 (n = 2^20: +1.3 ... 2 % in four same-box A/Bs), 0 below (+-1 %).  profiles/r4_ab_defer_*.txt
 #ifndef QUAD_ABL  // timing experiments only (tools/ab_quad.sh variants; results invalid): 1 no result stores, 2 no stage barrier in the column
-#define QUAD_ABL 0  // step, 4 none in the row step, 8 no column-step arithmetic, 16 no window stores, 32 no row-step arithmetic
+#define QUAD_ABL 0  // step, 4 none in the row step, 8 no column-step arithmetic, 16 no window stores, 32 no row-step arithmetic, 64 no landing barrier in the column step (with 2: its waves run free of each other)
 #endif
 #ifndef QUAD_FINE_TRACE  // profiling builds only: time stamps inside the column chunks of transform 3 (tools/quad_fine.py)
 #define QUAD_FINE_TRACE 0
@@ -502,7 +502,7 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
             if (it > 0 && a == 0) FFT_WAIT_VM_LE(4 * E / V + (QUAD_EARLY_CHUNK1 ? NCH : 0));  // (+ chunk 1's pieces, requested in round 3)
             else FFT_WAIT_VM0();
             }
-            FFT_SYNC_LDS();
+            if (!(QUAD_ABL & 64) || p.nb < 0) FFT_SYNC_LDS();
             ev();
             // the previous transform's results, part a.  QUAD_DEFER_STORES = 2: not by every wave at once -- a quarter of the waves at each of
             // four points of the chunk (here, behind stage 1's butterflies, behind the stage barrier, under stage 2's reads): the waves that
