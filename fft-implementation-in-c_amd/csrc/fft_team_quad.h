@@ -756,6 +756,8 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
                 // the next round's image is requested NOW (the other image was last read in round r - 1) and flies under this
                 // round's second stage; behind it the values of round r + 2, into the slot this round's image came from
                 // (everybody's image of round r has landed: arrival G + r + 2 says so)
+                // (requested at the START of the round instead -- the team wait right behind the arrival it waits for -- : -10 % at n = 2^20, -4 % at
+                // 2^19, profiles/r4_ab_early_request.txt: the wait then costs the seats' whole landing skew, here it hides behind stage 1)
                 wait_all(G + r + 2, r == 2);
                 ev();
                 dma_window((r + 1) & 1, (r + 1) & 1);
