@@ -566,7 +566,20 @@ def test_first_in_place_team_execute_runs_from_a_staged_copy(gpu_lib):
     assert np.array_equal(buf.download(x.shape, np.complex64), y1)
     plan.set_option(fftlib.OPT_TEAM_NO_REPLAY, 1)  # (accepted by plain 1D plans)
     plan.destroy()
+    # two in-place executes of a FRESH plan on two buffers before any sync: the first is staged, the second finds the staging area in use
+    # and runs unstaged -- both must be right
+    buf2 = fftlib.DeviceBuffer(x.nbytes)
+    plan = fftlib.Plan(n, batch, -1, np.complex64)
+    buf.upload(x)
+    buf2.upload(x[::-1].copy())
+    plan.execute_ptr(buf.ptr, buf.ptr)
+    plan.execute_ptr(buf2.ptr, buf2.ptr)
+    assert plan.team_status() == 0
+    assert np.array_equal(buf.download(x.shape, np.complex64), y1)
+    assert np.array_equal(buf2.download(x.shape, np.complex64), y1[::-1])
+    plan.destroy()
     buf.free()
+    buf2.free()
 
 
 def _team_plan(monkeypatch, n, batch, direction, dtype, mode="2"):
