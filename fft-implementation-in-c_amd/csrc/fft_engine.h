@@ -207,6 +207,8 @@ class Pow2Plan {
     bool team_proven = false;    // a sync has seen a team launch of this plan end with status OK: in-place executes are no longer staged
     cpx<T>* team_stage = nullptr;  // staged input of in-place executes until then (freed by the sync that proves the kernel)
     size_t team_stage_bytes = 0, team_stage_used = 0;
+    int team_suspend = 0;        // executes that still skip the team kernel after it fell back three times in a row (a shared or
+    int team_suspensions = 0;    // partitioned device): then it is tried again, with a short formation timeout; the pause doubles (64 ... 1024)
     bool team_disabled = false;  // a team wait timed out once: the team kernel is never enabled again for this plan
     int team_unrecoverable = 0;  // executes a timeout invalidated and recover_after_timeout could not repeat (since the last one)
     int team_fallbacks = 0;      // consecutive executes that ended in the two-pass fallback
@@ -588,7 +590,8 @@ class Pow2Plan {
         tp.o_sb1 = team.o_sb1; tp.o_sa2 = team.o_sa2; tp.o_sb2 = team.o_sb2; tp.o_t0 = team.o_t0; tp.o_t1 = team.o_t1;
         tp.sa1_bits = team.sa1_bits; tp.sa2_bits = team.sa2_bits; tp.t0_bits = team.t0_bits;
         tp.timeout_ticks = rt->team_timeout_ticks();
-        tp.form_timeout_ticks = rt->team_form_timeout_ticks();
+        // (after a fallback the next attempts give up ten times sooner: a device that is shared NOW mostly still is)
+        tp.form_timeout_ticks = (team_fallbacks > 0 || team_suspensions > 0) ? std::max<long long>(1, rt->team_form_timeout_ticks() / 10) : rt->team_form_timeout_ticks();
         tp.sticky = team.sticky;
         static const int ablate = FFT_EXP_ENV("FFT_HIP_TEAM_ABLATE") ? atoi(FFT_EXP_ENV("FFT_HIP_TEAM_ABLATE")) : 0;  // profiling only
         tp.ablate = ablate;
@@ -1565,7 +1568,8 @@ class Pow2Plan {
         // kernel's status word and return at once unless the teams could not be formed (nothing touched yet).
         run_if = nullptr;
         int mark0 = 0;
-        if (team.ok && nb >= team.min_batch) {
+        if (team.ok && nb >= team.min_batch && team_suspend > 0) team_suspend--;
+        else if (team.ok && nb >= team.min_batch) {
             // In place, and this plan's team kernel has never been seen to end well: run it from a copy of the input, so that a timeout
             // (a member that never arrives: status 2) can be repaired like an out-of-place execute -- fft_gpu_execute has no failure
             // mode (reference include/fft_gpu.h:102).  One device copy per such execute until the first sync proves the kernel; where

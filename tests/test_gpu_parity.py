@@ -727,6 +727,16 @@ def test_team_kernel_fallback_on_device(gpu_lib, monkeypatch):
         st = plan.team_status()
         assert st == 1, (it, st)  # the fourth execute no longer launches the team kernel: last known status stays 1
         assert rel(buf.download(x.shape, np.complex64)[:2], ref) <= TIGHT[np.dtype(np.complex64)]
+    # round 4: the kernel is paused, not retired -- 64 executes on the multi-pass schedule (the fourth above was the first of them), then it
+    # is tried again; the device is healthy now, so it does the work
+    plan.set_option(fftlib.OPT_TEAM_FORCE_FALLBACK, 0)
+    for it in range(63):
+        plan.execute_ptr(buf.ptr, buf.ptr)
+    assert plan.team_status() == 1  # still the last known status: nothing launched
+    buf.upload(x)
+    plan.execute_ptr(buf.ptr, buf.ptr)
+    assert plan.team_status() == 0
+    assert rel(buf.download(x.shape, np.complex64)[:2], ref) <= TIGHT[np.dtype(np.complex64)]
     plan.destroy()
     buf.free()
 
