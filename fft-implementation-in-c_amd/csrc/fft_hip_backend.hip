@@ -914,22 +914,29 @@ double fft_gpu_stream_bench_hip(size_t bytes, int iters, int mode) {
     fftk::vec16<float>* out = (fftk::vec16<float>*)b;
     double best = -1.0;
     // shapes 0 - 11: grid-stride (1 / 4 / 8 accesses in flight x 8 / 16 workgroups per CU x plain / nt); 12 (copy only): the LDS-DMA tile
-    // copy; 13 - 18: tile-wise streams in the single-pass FFT kernels' shape, 4 / 6 / 8 workgroups per CU x plain / nt
-    const int n_shapes = 19;
+    // copy; 13 - 30: tile-wise streams in the single-pass FFT kernels' shape: tiles of 16 / 32 / 64 KiB (4 / 8 / 16 accesses in flight per
+    // thread) x 2 / 4 / 8 workgroups per CU x plain / nt
+    const int n_shapes = 31;
+    static const bool verbose = FFT_EXP_ENV("FFT_HIP_STREAM_VERBOSE") != nullptr;  // (the experiments build: every shape's rate on stderr)
     for (int shape = 0; shape < n_shapes; shape++) {
         if (shape == 12 && mode != 0) continue;
-        const int per_cu = shape >= 13 ? (4 + 2 * ((shape - 13) % 3)) : (shape / 3) % 2 ? 16 : 8;  // resident 256-thread workgroups per CU
-        const bool nt = shape >= 13 ? shape >= 16 : shape >= 6;
+        const int ts = shape - 13;  // tile shapes: (ts % 3) -> workgroups per CU, (ts / 3) % 3 -> tile size, ts / 9 -> nt
+        const int tile_u = shape >= 13 ? (4 << ((ts / 3) % 3)) : 8;
+        const int per_cu = shape >= 13 ? (2 << (ts % 3)) : (shape / 3) % 2 ? 16 : 8;  // resident 256-thread workgroups per CU
+        const bool nt = shape >= 13 ? ts >= 9 : shape >= 6;
         const unsigned grid = (unsigned)(cus * per_cu);
         for (int rep = 0; rep < 2; rep++) {
             (void)hipEventRecord(e0, nullptr);
             for (int it = 0; it < iters; it++) {
                 if (shape >= 13) {
-                    const long long n_tiles = (long long)(bytes / 32768);
-#define FFT_TILE_LAUNCH(M) do { if (nt) hipLaunchKernelGGL((fftk::stream_tile_kernel<M, 1>), dim3(grid), dim3(256), 0, nullptr, in, out, n_tiles); \
-                                else hipLaunchKernelGGL((fftk::stream_tile_kernel<M, 0>), dim3(grid), dim3(256), 0, nullptr, in, out, n_tiles); } while (0)
+                    const long long n_tiles = (long long)(bytes / (4096 * (size_t)tile_u));
+#define FFT_TILE_LAUNCH2(M, N, U) hipLaunchKernelGGL((fftk::stream_tile_kernel<M, N, U>), dim3(grid), dim3(256), 0, nullptr, in, out, n_tiles)
+#define FFT_TILE_LAUNCH1(M, N) do { if (tile_u == 4) FFT_TILE_LAUNCH2(M, N, 4); else if (tile_u == 8) FFT_TILE_LAUNCH2(M, N, 8); else FFT_TILE_LAUNCH2(M, N, 16); } while (0)
+#define FFT_TILE_LAUNCH(M) do { if (nt) FFT_TILE_LAUNCH1(M, 1); else FFT_TILE_LAUNCH1(M, 0); } while (0)
                     if (mode == 0) FFT_TILE_LAUNCH(0); else if (mode == 1) FFT_TILE_LAUNCH(1); else FFT_TILE_LAUNCH(2);
 #undef FFT_TILE_LAUNCH
+#undef FFT_TILE_LAUNCH1
+#undef FFT_TILE_LAUNCH2
                     continue;
                 }
                 if (shape == 12) {
@@ -955,6 +962,7 @@ double fft_gpu_stream_bench_hip(size_t bytes, int iters, int mode) {
             (void)hipEventElapsedTime(&ms, e0, e1);
             if (rep == 1 && ms > 0.f) {
                 const double gbs = (mode == 0 ? 2.0 : 1.0) * (double)bytes * iters / (ms * 1e-3) / 1e9;
+                if (verbose) fprintf(stderr, "stream bench mode %d shape %2d: %7.1f GB/s\n", mode, shape, gbs);
                 if (gbs > best) best = gbs;
             }
         }

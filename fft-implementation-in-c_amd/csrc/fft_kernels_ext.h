@@ -179,40 +179,40 @@ FFT_KERNEL void FFT_LAUNCH_BOUNDS(256) stream16_kernel(const vec16<float>* in, v
 }
 
 // The streams in the shape of the single-pass FFT kernels (whose n = 512 instance moves 6.1 TB/s, more than any grid-stride shape above
-// reached -- round-3 review): a 256-thread workgroup walks 32 KiB tiles `tile = block, block + grid, ..`; per tile a thread has eight
+// reached -- round-3 review): a 256-thread workgroup walks tiles of U x 4 KiB `tile = block, block + grid, ..`; per tile a thread has U
 // 16-byte accesses in flight, a wave instruction covers 1 KiB, and the NEXT tile's loads are issued before this tile's stores
 // (MODE as above).
-template <int MODE, int NT>
+template <int MODE, int NT, int U = 8>
 FFT_KERNEL void FFT_LAUNCH_BOUNDS(256) stream_tile_kernel(const vec16<float>* in, vec16<float>* out, long long n_tiles) {
     const int tid = FFT_TID;
     vec16<float> acc;
     acc.c[0] = mk<float>(0.f, 0.f);
     acc.c[1] = mk<float>(1.f, 2.f);
-    vec16<float> cur[8], nxt[8];
+    vec16<float> cur[U], nxt[U];  // tiles of U x 4 KiB
     long long t = FFT_BID;
     if (MODE != 2 && t < n_tiles) {
         FFT_UNROLL
-        for (int i = 0; i < 8; i++) cur[i] = fft_ld16<NT>(in + t * 2048 + i * 256 + tid);
+        for (int i = 0; i < U; i++) cur[i] = fft_ld16<NT>(in + t * (U * 256) + i * 256 + tid);
     }
     for (; t < n_tiles; t += FFT_NBLOCKS) {
         const long long tn = t + FFT_NBLOCKS;
         if (MODE != 2 && tn < n_tiles) {
             FFT_UNROLL
-            for (int i = 0; i < 8; i++) nxt[i] = fft_ld16<NT>(in + tn * 2048 + i * 256 + tid);
+            for (int i = 0; i < U; i++) nxt[i] = fft_ld16<NT>(in + tn * (U * 256) + i * 256 + tid);
         }
         if (MODE == 1) {
             FFT_UNROLL
-            for (int i = 0; i < 8; i++) {
+            for (int i = 0; i < U; i++) {
                 acc.c[0].re += cur[i].c[0].re;
                 acc.c[0].im += cur[i].c[1].im;
             }
         } else {
             FFT_UNROLL
-            for (int i = 0; i < 8; i++) fft_st16<NT>(out + t * 2048 + i * 256 + tid, MODE == 2 ? acc : cur[i]);
+            for (int i = 0; i < U; i++) fft_st16<NT>(out + t * (U * 256) + i * 256 + tid, MODE == 2 ? acc : cur[i]);
         }
         if (MODE != 2) {
             FFT_UNROLL
-            for (int i = 0; i < 8; i++) cur[i] = nxt[i];
+            for (int i = 0; i < U; i++) cur[i] = nxt[i];
         }
     }
     if (MODE == 1 && acc.c[0].re != acc.c[0].re && acc.c[0].im == 12345.f) out[0] = acc;
