@@ -1,6 +1,8 @@
 """Timeline of team_quad_kernel (fft_team_quad.h) from its in-kernel clock log.  python tools/quad_trace.py [batch]
 Events per workgroup: 0 = team formed; per transform 16: the four column chunks landed, combine done, round-0 values in L2
-(arrival), then per round: team wait over, image landed; final radix-4 done, result stores issued."""
+(arrival), then per round: team wait over, image landed; final radix-4 done, result stores issued.  Round 4: on teams of 32 the result
+stores of a transform are issued in front of the NEXT transform's column chunks (QUAD_DEFER_STORES): the last two events then coincide
+and the store time shows up in the chunk events of the following transform."""
 import os
 import sys
 
