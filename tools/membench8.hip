@@ -1,0 +1,114 @@
+// membench8.hip -- what does the memory side sustain for team_quad_kernel's TRAFFIC MIX when nothing waits for anybody?  (measurement tool,
+// round 4.)  Per transform of n = 2^20 fp32 a CU of the team moves four streams of 256 KiB each through its one vector-memory queue: HBM in
+// (LDS-DMA, nt), window out (plain 16-byte stores into the XCD's L2), window in (LDS-DMA, sc1 nt), HBM out (nt stores).  The kernel below issues
+// exactly those instructions, 64 KiB of each per "quarter", with the same LDS double buffering -- and NO arithmetic, NO team protocol, NO
+// dependency between the streams except the LDS images' reuse: the data is garbage, the traffic is real.  One 512-thread workgroup per CU.
+//   mode bit 0: HBM in   bit 1: window out   bit 2: window in   bit 3: HBM out      (15 = all four)
+//   window bytes per XCD: `slots` x 2 MiB (every workgroup writes the image of the workgroup 8 blocks on -- same XCD under round-robin
+//   dispatch -- and reads its own)
+// Prints the time per "transform" (4 quarters) per CU and the Gpoint/s the batch of BASELINE config 3 would run at that pace.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+template <int POL>  // 0: HBM stream, nt; 1: window, sc1 nt
+__device__ __forceinline__ void dma(const u32x4* p, unsigned lds) {
+    const unsigned a = __builtin_amdgcn_readfirstlane(lds);
+    unsigned saved;
+    if (POL == 0)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0" : "=&s"(saved) : "v"(p), "s"(a) : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off sc1 nt\n\ts_mov_b32 m0, %0" : "=&s"(saved) : "v"(p), "s"(a) : "memory");
+}
+__device__ __forceinline__ void st_nt(u32x4* p, u32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void st_plain(u32x4* p, u32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(v) : "memory"); }
+
+__global__ __launch_bounds__(512) void k_mix(const u32x4* in, u32x4* out, u32x4* window, int transforms, int mode, int slots, long long* clocks) {
+    extern __shared__ u32x4 land[];  // 2 x 64 KiB
+    const unsigned tid = threadIdx.x;
+    const unsigned lds0 = (unsigned)(size_t)land;
+    const long long wg = blockIdx.x, nwg = gridDim.x;
+    const u32x4 v = {tid, 1u, 2u, 3u};
+    // the window of "my" XCD (blocks b, b + 8, ..): slot x 32 images of 4096 pieces; I write the image of block (b + 8) and read mine
+    const long long xcd = wg % 8, seat = wg / 8, seat_to = (seat + 1) % (nwg / 8);
+    u32x4* const win = window + xcd * ((long long)slots * (nwg / 8) * 4096);
+    if (tid == 0) clocks[wg * 2] = (long long)wall_clock64();
+    int im = 0;
+    for (int t = 0; t < transforms; t++) {
+        // my transform: rows of 8 KiB (512 pieces), my 16 pieces (256 bytes) of each: the column-step and result pattern of n = 2^20
+        const long long tr = t;  // (every XCD walks its own transforms: xcd, xcd + 8, ..)
+        const u32x4* src_t = in + ((tr * 8 + xcd) % 512) * (1024ll * 512) + seat * 16;
+        u32x4* dst_t = out + ((tr * 8 + xcd) % 512) * (1024ll * 512) + seat * 16;
+        for (int q = 0; q < 4; q++, im ^= 1) {
+            const unsigned base = lds0 + (unsigned)im * 65536u;
+            if (mode & 1) {  // HBM in: 256 rows (every fourth of the 1024) x 256 bytes
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const int piece = i * 512 + (int)tid;
+                    dma<0>(src_t + (long long)(4 * (piece >> 4) + q) * 512 + (piece & 15), base + (unsigned)(i * 512 + (tid & ~63u)) * 16u);
+                }
+            }
+            if (mode & 2) {  // window out: 64 KiB into a neighbour's image of slot (q mod slots), 1 KiB runs
+                u32x4* w = win + ((long long)(q % slots) * (nwg / 8) + seat_to) * 4096 + tid;
+#pragma unroll
+                for (int i = 0; i < 8; i++) st_plain(w + i * 512, v);
+            }
+            if (mode & 4) {  // window in: my image of the other slot
+                const u32x4* w = win + ((long long)((q + 1) % slots) * (nwg / 8) + seat) * 4096 + tid;
+#pragma unroll
+                for (int i = 0; i < 8; i++) dma<1>(w + i * 512, base + (unsigned)(i * 512 + (tid & ~63u)) * 16u);
+            }
+            if (mode & 8) {  // HBM out: 256 rows x 256 bytes, 16-byte stores, nt
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const int piece = i * 512 + (int)tid;
+                    st_nt(dst_t + (long long)(4 * (piece >> 4) + q) * 512 + (piece & 15), v);
+                }
+            }
+            // the image written two quarters ago is reused next: everything older than this quarter's instructions has completed
+            switch (__builtin_popcount(mode & 15)) {
+                case 1: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+                case 2: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+                case 3: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+                default: asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); break;
+            }
+            __syncthreads();
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) clocks[wg * 2 + 1] = (long long)wall_clock64();
+}
+
+int main() {
+    const int nwg = 256, transforms = 64;  // 64 "transforms" per XCD = BASELINE config 3's 512 over 8 XCDs
+    u32x4 *in, *out, *window; long long* clocks;
+    const size_t tbytes = 512ull * 1024 * 512 * 16;  // 512 transforms of 8 MiB
+    CK(hipMalloc(&in, tbytes)); CK(hipMalloc(&out, tbytes));
+    CK(hipMemset(in, 1, tbytes)); CK(hipMemset(out, 0, tbytes));
+    CK(hipMalloc(&window, 8ull * 2 * 32 * 65536)); CK(hipMemset(window, 0, 8ull * 2 * 32 * 65536));
+    CK(hipMalloc(&clocks, nwg * 2 * sizeof(long long)));
+    CK(hipFuncSetAttribute((const void*)k_mix, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    struct { int mode, slots; const char* name; } cases[] = {
+        {15, 2, "all four streams, window 4 MiB per XCD"}, {15, 1, "all four streams, window 2 MiB per XCD"},
+        {9, 2, "HBM in + HBM out only"}, {6, 2, "window out + in only (4 MiB)"}, {6, 1, "window out + in only (2 MiB)"},
+        {1, 2, "HBM in only"}, {8, 2, "HBM out only"}, {7, 2, "HBM in + window (4 MiB), no HBM out"}, {14, 2, "window (4 MiB) + HBM out, no HBM in"}};
+    for (auto& c : cases) {
+        float best = 1e30f;
+        for (int rep = 0; rep < 4; rep++) {
+            CK(hipEventRecord(e0));
+            hipLaunchKernelGGL(k_mix, dim3(nwg), dim3(512), 131072, 0, in, out, window, transforms, c.mode, c.slots, clocks);
+            CK(hipEventRecord(e1));
+            CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            if (rep > 0 && ms < best) best = ms;
+        }
+        const double us_per_transform = best * 1e3 / transforms;
+        printf("%-48s %7.3f ms per 512 transforms = %6.2f us per transform and XCD = %6.1f Gpoint/s at that pace (%4.1f %% of the 8 TB/s roof)\n", c.name, best,
+               us_per_transform, 512.0 * 1048576 / best / 1e6, 512.0 * 1048576 * 16 / best / 1e6 / 80);
+    }
+    return 0;
+}
