@@ -4,8 +4,8 @@
 // exactly those instructions, 64 KiB of each per "quarter", with the same LDS double buffering -- and NO arithmetic, NO team protocol, NO
 // dependency between the streams except the LDS images' reuse: the data is garbage, the traffic is real.  One 512-thread workgroup per CU.
 //   mode bit 0: HBM in   bit 1: window out   bit 2: window in   bit 3: HBM out      (15 = all four)
-//   window bytes per XCD: `slots` x 2 MiB (every workgroup writes the image of the workgroup 8 blocks on -- same XCD under round-robin
-//   dispatch -- and reads its own)
+//   window bytes per XCD: a ring of `slots` units of 1 MiB (every workgroup writes half images of the workgroup 8 blocks on -- same XCD under
+//   round-robin dispatch -- and reads its own, written `lag` units earlier)
 // Prints the time per "transform" (4 quarters) per CU and the Gpoint/s the batch of BASELINE config 3 would run at that pace.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -25,7 +25,7 @@ __device__ __forceinline__ void dma(const u32x4* p, unsigned lds) {
 __device__ __forceinline__ void st_nt(u32x4* p, u32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(v) : "memory"); }
 __device__ __forceinline__ void st_plain(u32x4* p, u32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(v) : "memory"); }
 
-__global__ __launch_bounds__(512) void k_mix(const u32x4* in, u32x4* out, u32x4* window, int transforms, int mode, int slots, long long* clocks) {
+__global__ __launch_bounds__(512) void k_mix(const u32x4* in, u32x4* out, u32x4* window, int transforms, int mode, int slots, int lag, long long* clocks) {
     extern __shared__ u32x4 land[];  // 2 x 64 KiB
     const unsigned tid = threadIdx.x;
     const unsigned lds0 = (unsigned)(size_t)land;
@@ -33,7 +33,7 @@ __global__ __launch_bounds__(512) void k_mix(const u32x4* in, u32x4* out, u32x4*
     const u32x4 v = {tid, 1u, 2u, 3u};
     // the window of "my" XCD (blocks b, b + 8, ..): slot x 32 images of 4096 pieces; I write the image of block (b + 8) and read mine
     const long long xcd = wg % 8, seat = wg / 8, seat_to = (seat + 1) % (nwg / 8);
-    u32x4* const win = window + xcd * ((long long)slots * (nwg / 8) * 4096);
+    u32x4* const win = window + xcd * ((long long)slots * (nwg / 8) * 2048);
     if (tid == 0) clocks[wg * 2] = (long long)wall_clock64();
     int im = 0;
     for (int t = 0; t < transforms; t++) {
@@ -50,15 +50,22 @@ __global__ __launch_bounds__(512) void k_mix(const u32x4* in, u32x4* out, u32x4*
                     dma<0>(src_t + (long long)(4 * (piece >> 4) + q) * 512 + (piece & 15), base + (unsigned)(i * 512 + (tid & ~63u)) * 16u);
                 }
             }
-            if (mode & 2) {  // window out: 64 KiB into a neighbour's image of slot (q mod slots), 1 KiB runs
-                u32x4* w = win + ((long long)(q % slots) * (nwg / 8) + seat_to) * 4096 + tid;
+            // the window as a ring of `slots` units of 1 MiB per XCD (32 KiB per workgroup and unit): a quarter writes two units and
+            // reads the two units written `lag` units earlier
+            const long long h0 = ((long long)t * 4 + q) * 2;
+            if (mode & 2) {  // window out: 2 x 32 KiB into a neighbour's half images, 1 KiB runs
 #pragma unroll
-                for (int i = 0; i < 8; i++) st_plain(w + i * 512, v);
+                for (int i = 0; i < 8; i++) {
+                    u32x4* w = win + (((h0 + (i >> 2)) % slots) * (nwg / 8) + seat_to) * 2048 + tid;
+                    st_plain(w + (i & 3) * 512, v);
+                }
             }
-            if (mode & 4) {  // window in: my image of the other slot
-                const u32x4* w = win + ((long long)((q + 1) % slots) * (nwg / 8) + seat) * 4096 + tid;
+            if (mode & 4) {  // window in: my half images, written `lag` units ago
 #pragma unroll
-                for (int i = 0; i < 8; i++) dma<1>(w + i * 512, base + (unsigned)(i * 512 + (tid & ~63u)) * 16u);
+                for (int i = 0; i < 8; i++) {
+                    const u32x4* w = win + (((h0 + (i >> 2) + slots - lag % slots) % slots) * (nwg / 8) + seat) * 2048 + tid;
+                    dma<1>(w + (i & 3) * 512, base + (unsigned)(i * 512 + (tid & ~63u)) * 16u);
+                }
             }
             if (mode & 8) {  // HBM out: 256 rows x 256 bytes, 16-byte stores, nt
 #pragma unroll
@@ -88,19 +95,23 @@ int main() {
     const size_t tbytes = 512ull * 1024 * 512 * 16;  // 512 transforms of 8 MiB
     CK(hipMalloc(&in, tbytes)); CK(hipMalloc(&out, tbytes));
     CK(hipMemset(in, 1, tbytes)); CK(hipMemset(out, 0, tbytes));
-    CK(hipMalloc(&window, 8ull * 2 * 32 * 65536)); CK(hipMemset(window, 0, 8ull * 2 * 32 * 65536));
+    CK(hipMalloc(&window, 8ull * 8 * 32 * 32768)); CK(hipMemset(window, 0, 8ull * 8 * 32 * 32768));
     CK(hipMalloc(&clocks, nwg * 2 * sizeof(long long)));
     CK(hipFuncSetAttribute((const void*)k_mix, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    struct { int mode, slots; const char* name; } cases[] = {
-        {15, 2, "all four streams, window 4 MiB per XCD"}, {15, 1, "all four streams, window 2 MiB per XCD"},
-        {9, 2, "HBM in + HBM out only"}, {6, 2, "window out + in only (4 MiB)"}, {6, 1, "window out + in only (2 MiB)"},
-        {1, 2, "HBM in only"}, {8, 2, "HBM out only"}, {7, 2, "HBM in + window (4 MiB), no HBM out"}, {14, 2, "window (4 MiB) + HBM out, no HBM in"}};
+    struct { int mode, slots, lag; const char* name; } cases[] = {
+        {15, 4, 4, "all four streams, window 4 MiB per XCD"}, {15, 3, 3, "all four streams, window 3 MiB per XCD"},
+        {15, 2, 2, "all four streams, window 2 MiB per XCD"}, {15, 1, 1, "all four streams, window 1 MiB per XCD"},
+        {15, 6, 6, "all four streams, window 6 MiB per XCD"}, {15, 8, 8, "all four streams, window 8 MiB per XCD"},
+        {15, 4, 2, "all four, ring of 4 MiB, read 2 units behind"}, {15, 4, 1, "all four, ring of 4 MiB, read 1 unit behind"},
+        {9, 2, 2, "HBM in + HBM out only"}, {6, 4, 4, "window out + in only (4 MiB)"}, {6, 2, 2, "window out + in only (2 MiB)"},
+        {1, 2, 2, "HBM in only"}, {8, 2, 2, "HBM out only"}, {7, 4, 4, "HBM in + window (4 MiB), no HBM out"}, {14, 4, 4, "window (4 MiB) + HBM out, no HBM in"},
+        {7, 2, 2, "HBM in + window (2 MiB), no HBM out"}, {14, 2, 2, "window (2 MiB) + HBM out, no HBM in"}};
     for (auto& c : cases) {
         float best = 1e30f;
         for (int rep = 0; rep < 4; rep++) {
             CK(hipEventRecord(e0));
-            hipLaunchKernelGGL(k_mix, dim3(nwg), dim3(512), 131072, 0, in, out, window, transforms, c.mode, c.slots, clocks);
+            hipLaunchKernelGGL(k_mix, dim3(nwg), dim3(512), 131072, 0, in, out, window, transforms, c.mode, c.slots, c.lag, clocks);
             CK(hipEventRecord(e1));
             CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
