@@ -24,8 +24,36 @@ __device__ __forceinline__ void dma(const u32x4* p, unsigned lds) {
 }
 __device__ __forceinline__ void st_nt(u32x4* p, u32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(v) : "memory"); }
 __device__ __forceinline__ void st_plain(u32x4* p, u32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(v) : "memory"); }
+// cache-policy bits chosen at run time (wave-uniform): 0 plain, 1 nt, 2 sc1, 3 sc1 nt, 4 sc0 sc1, 5 sc0 sc1 nt, 6 sc0, 7 sc0 nt
+__device__ __forceinline__ void st_pol(u32x4* p, u32x4 v, int pol) {
+    switch (pol) {
+        case 1: asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(v) : "memory"); break;
+        case 2: asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); break;
+        case 3: asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(p), "v"(v) : "memory"); break;
+        case 4: asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); break;
+        case 5: asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(p), "v"(v) : "memory"); break;
+        case 6: asm volatile("global_store_dwordx4 %0, %1, off sc0" ::"v"(p), "v"(v) : "memory"); break;
+        case 7: asm volatile("global_store_dwordx4 %0, %1, off sc0 nt" ::"v"(p), "v"(v) : "memory"); break;
+        default: asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(v) : "memory"); break;
+    }
+}
+#define DMA_ASM(bits) asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off " bits "\n\ts_mov_b32 m0, %0" : "=&s"(saved) : "v"(p), "s"(a) : "memory")
+__device__ __forceinline__ void dma_pol(const u32x4* p, unsigned lds, int pol) {
+    const unsigned a = __builtin_amdgcn_readfirstlane(lds);
+    unsigned saved;
+    switch (pol) {
+        case 1: DMA_ASM("nt"); break;
+        case 2: DMA_ASM("sc1"); break;
+        case 3: DMA_ASM("sc1 nt"); break;
+        case 4: DMA_ASM("sc0 sc1"); break;
+        case 5: DMA_ASM("sc0 sc1 nt"); break;
+        case 6: DMA_ASM("sc0"); break;
+        case 7: DMA_ASM("sc0 nt"); break;
+        default: DMA_ASM(""); break;
+    }
+}
 
-__global__ __launch_bounds__(512) void k_mix(const u32x4* in, u32x4* out, u32x4* window, int transforms, int mode, int slots, int lag, long long* clocks) {
+__global__ __launch_bounds__(512) void k_mix(const u32x4* in, u32x4* out, u32x4* window, int transforms, int mode, int slots, int lag, long long* clocks, int p_in, int p_wst, int p_wld, int p_out) {
     extern __shared__ u32x4 land[];  // 2 x 64 KiB
     const unsigned tid = threadIdx.x;
     const unsigned lds0 = (unsigned)(size_t)land;
@@ -47,7 +75,7 @@ __global__ __launch_bounds__(512) void k_mix(const u32x4* in, u32x4* out, u32x4*
 #pragma unroll
                 for (int i = 0; i < 8; i++) {
                     const int piece = i * 512 + (int)tid;
-                    dma<0>(src_t + (long long)(4 * (piece >> 4) + q) * 512 + (piece & 15), base + (unsigned)(i * 512 + (tid & ~63u)) * 16u);
+                    dma_pol(src_t + (long long)(4 * (piece >> 4) + q) * 512 + (piece & 15), base + (unsigned)(i * 512 + (tid & ~63u)) * 16u, p_in);
                 }
             }
             // the window as a ring of `slots` units of 1 MiB per XCD (32 KiB per workgroup and unit): a quarter writes two units and
@@ -57,21 +85,21 @@ __global__ __launch_bounds__(512) void k_mix(const u32x4* in, u32x4* out, u32x4*
 #pragma unroll
                 for (int i = 0; i < 8; i++) {
                     u32x4* w = win + (((h0 + (i >> 2)) % slots) * (nwg / 8) + seat_to) * 2048 + tid;
-                    st_plain(w + (i & 3) * 512, v);
+                    st_pol(w + (i & 3) * 512, v, p_wst);
                 }
             }
             if (mode & 4) {  // window in: my half images, written `lag` units ago
 #pragma unroll
                 for (int i = 0; i < 8; i++) {
                     const u32x4* w = win + (((h0 + (i >> 2) + slots - lag % slots) % slots) * (nwg / 8) + seat) * 2048 + tid;
-                    dma<1>(w + (i & 3) * 512, base + (unsigned)(i * 512 + (tid & ~63u)) * 16u);
+                    dma_pol(w + (i & 3) * 512, base + (unsigned)(i * 512 + (tid & ~63u)) * 16u, p_wld);
                 }
             }
             if (mode & 8) {  // HBM out: 256 rows x 256 bytes, 16-byte stores, nt
 #pragma unroll
                 for (int i = 0; i < 8; i++) {
                     const int piece = i * 512 + (int)tid;
-                    st_nt(dst_t + (long long)(4 * (piece >> 4) + q) * 512 + (piece & 15), v);
+                    st_pol(dst_t + (long long)(4 * (piece >> 4) + q) * 512 + (piece & 15), v, p_out);
                 }
             }
             // the image written two quarters ago is reused next: everything older than this quarter's instructions has completed
@@ -111,7 +139,7 @@ int main() {
         float best = 1e30f;
         for (int rep = 0; rep < 4; rep++) {
             CK(hipEventRecord(e0));
-            hipLaunchKernelGGL(k_mix, dim3(nwg), dim3(512), 131072, 0, in, out, window, transforms, c.mode, c.slots, c.lag, clocks);
+            hipLaunchKernelGGL(k_mix, dim3(nwg), dim3(512), 131072, 0, in, out, window, transforms, c.mode, c.slots, c.lag, clocks, 1, 0, 3, 1);
             CK(hipEventRecord(e1));
             CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
@@ -120,6 +148,26 @@ int main() {
         const double us_per_transform = best * 1e3 / transforms;
         printf("%-48s %7.3f ms per 512 transforms = %6.2f us per transform and XCD = %6.1f Gpoint/s at that pace (%4.1f %% of the 8 TB/s roof)\n", c.name, best,
                us_per_transform, 512.0 * 1048576 / best / 1e6, 512.0 * 1048576 * 16 / best / 1e6 / 80);
+    }
+    // cache-policy bits of the four streams at 4 MiB and at 3 MiB of window (the kernel's: in nt, window stores plain, window loads sc1 nt, out nt)
+    const char* pn[8] = {"plain", "nt", "sc1", "sc1 nt", "sc0 sc1", "sc0 sc1 nt", "sc0", "sc0 nt"};
+    for (int slots : {4, 3}) {
+        printf("---- policy matrix, window %d MiB: in | window store | window load | out : ms\n", slots);
+        for (int p_in : {1, 0, 3, 5})
+            for (int p_wst : {0, 1})
+                for (int p_wld : {3, 2, 1, 0})
+                    for (int p_out : {1, 0, 2, 3, 4, 5}) {
+                        float best = 1e30f;
+                        for (int rep = 0; rep < 3; rep++) {
+                            CK(hipEventRecord(e0));
+                            hipLaunchKernelGGL(k_mix, dim3(nwg), dim3(512), 131072, 0, in, out, window, transforms, 15, slots, slots, clocks, p_in, p_wst, p_wld, p_out);
+                            CK(hipEventRecord(e1));
+                            CK(hipEventSynchronize(e1));
+                            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                            if (rep > 0 && ms < best) best = ms;
+                        }
+                        printf("%-10s | %-5s | %-10s | %-10s : %6.3f\n", pn[p_in], pn[p_wst], pn[p_wld], pn[p_out], best);
+                    }
     }
     return 0;
 }
