@@ -82,6 +82,11 @@ bool test_drop();   // test hook: this workgroup leaves right after the team has
 #define FFT_L2_COUNT_POLL(p) __atomic_load_n((p), __ATOMIC_SEQ_CST)
 // the counter and the word behind it (read AFTER the counter): low half = counter, high half = that word
 #define FFT_L2_COUNT_POLL2(p) ((unsigned long long)__atomic_load_n((p), __ATOMIC_SEQ_CST) | ((unsigned long long)__atomic_load_n((p) + 1, __ATOMIC_SEQ_CST) << 32))
+// the pair protocol of team_quad_kernel (SLOTS = 3): 8 bytes stored / loaded as one; the unit that signals and guards for itself (a wave
+// on the device, a thread here: host threads of a "wave" do not run in lockstep)
+#define FFT_L2_STORE64(p, lo, hi) __atomic_store_n((unsigned long long*)(p), (unsigned long long)(lo) | ((unsigned long long)(hi) << 32), __ATOMIC_SEQ_CST)
+#define FFT_L2_LOAD64(p) __atomic_load_n((const unsigned long long*)(p), __ATOMIC_SEQ_CST)
+#define FFT_PAIR_UNIT 1
 #define FFT_LDS_FRESH() __atomic_thread_fence(__ATOMIC_SEQ_CST)
 #define FFT_SCHED_BARRIER() ((void)0)
 #define FFT_WAIT_VM0() __atomic_thread_fence(__ATOMIC_SEQ_CST)
@@ -203,6 +208,22 @@ __device__ __forceinline__ unsigned long long fft_scalar_load2_glc(const unsigne
     asm volatile("s_load_dwordx2 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
     return v;
 }
+// the pair protocol of team_quad_kernel (SLOTS = 3): 8 bytes stored / loaded as one (p 8-byte aligned), eight adjacent words in one scalar
+// load (p 32-byte aligned); the unit that signals and guards for itself is a wave
+#define FFT_L2_STORE64(p, lo, hi) fft_l2_store64((unsigned*)(p), (unsigned)(lo), (unsigned)(hi))
+__device__ __forceinline__ void fft_l2_store64(unsigned* p, unsigned lo, unsigned hi) {
+    typedef unsigned fft_u32x2_ __attribute__((ext_vector_type(2)));
+    const fft_u32x2_ v = {lo, hi};
+    asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(p), "v"(v) : "memory");
+}
+#define FFT_L2_LOAD64(p) fft_scalar_load2_glc((const unsigned*)(p))
+typedef unsigned fft_u32x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ fft_u32x8 fft_scalar_load8_glc(const unsigned* p) {
+    fft_u32x8 v;
+    asm volatile("s_load_dwordx8 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+    return v;
+}
+#define FFT_PAIR_UNIT 64
 // the next read of a (non-volatile) LDS word is a real ds_read: volatile accesses through a pointer whose address
 // space the compiler has to infer come out as FLAT loads, which wait on vmcnt as well
 #define FFT_LDS_FRESH() asm volatile("" ::: "memory")

@@ -237,9 +237,10 @@ FFT_DEVICE void quad_twiddle_kb(cpx<T> (&x)[E], const cpx<T> (&v)[E], const cpx<
 // (n = 2^16) +6.5 % with one slot, teams of 8 (2^18) +-1 %, teams of 32 (2^20) -20 %.
 template <typename T, int E, int LOG2RA, int LOG2RB, int LOG2L1, int LOG2L2, int LOG2TS, int SLOTS>
 FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamParams<T> p) {
-    constexpr bool QUAD_ONE_SLOT = SLOTS == 1;
+    constexpr bool PAIR = SLOTS == 3;  // one image per seat in the window, per-seat counters instead of the team's (see `pair_guard`)
+    constexpr bool QUAD_ONE_SLOT = SLOTS == 1 || PAIR;
     constexpr int DEFER = QUAD_DEFER_STORES >= 0 ? QUAD_DEFER_STORES : ((LOG2TS >= 5 && sizeof(T) == 4) ? 1 : 0);
-    static_assert(SLOTS == 1 || SLOTS == 2, "one or two window slots");
+    static_assert(SLOTS == 1 || SLOTS == 2 || SLOTS == 3, "one or two window slots, or one with the pair protocol");
     constexpr int V = vec16<T>::V;  // values per 16-byte access: 2 (fp32: the values of two adjacent rows travel together), 1 (fp64)
     using S = QuadShape<E, LOG2RA, LOG2RB, LOG2L1, LOG2L2, LOG2TS>;
     constexpr int L1 = S::L1, L2 = S::L2, TS = S::TS, MA = S::MA, MB = S::MB, NC = S::NC, LOG2NC = S::LOG2NC, NR = S::NR, LOG2NR = S::LOG2NR;
@@ -288,7 +289,7 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
     if (team >= p.nb) return;  // more teams than transforms
     if (FFT_TEST_DROP()) return;  // emulation only: a member that never arrives
 
-    unsigned char* const sbase = p.scratch + (size_t)team * SLOTS * SLOT;
+    unsigned char* const sbase = p.scratch + (size_t)team * (PAIR ? 1 : SLOTS) * SLOT;
     // profiling only (experiments build, results invalid): the second slot aliases half (bit 16) or all (bit 32) of the first -- the
     // two-slot protocol on a window of 3 / 2 MiB per XCD instead of 4: what a smaller window would be worth
     const size_t slot_stride = FFT_ABLATE(p.ablate & 32) ? 0 : FFT_ABLATE(p.ablate & 16) ? SLOT / 2 : SLOT;
@@ -336,6 +337,101 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
     };
     auto arrive = [&]() __attribute__((always_inline)) {  // call behind a workgroup barrier, every wave's stores complete
         if (tid == 0) FFT_L2_COUNT_ADD(flags);
+    };
+    // ---- SLOTS = 3, the pair protocol: ONE image per seat in the window (2 MiB per XCD at n = 2^20 -- it stays in the L2, which the two slots
+    // of the team protocol do not: tools/membench8.hip) and no team-wide wait.  Rounds are numbered through the launch, R = 4 it + r.
+    //   * a sender UNIT (a wave on the device: its store instruction i goes to ONE seat) tells each seat it has written to, as soon as ITS
+    //     stores are complete -- no workgroup barrier --: one atomic add per store instruction on the seat's counter `rcv`;
+    //   * a seat pulls its image of round R when its own counter says that all (R + 1) x CNT instructions are in, and says so in its word of
+    //     the team's `landed` line (a plain store of R + 1);
+    //   * a unit writes round R into a seat's image when that seat's word says R (rounds < R have landed): it reads the words of the seats
+    //     it is about to write to -- on the device the eight adjacent words of its quarter of the team in ONE scalar load.
+    // A seat waits for its own 64 sender waves and a wave for its own 8 receivers, never for the slowest of the whole team: the store -> pull
+    // chain is 3.6 us against 5.4 with the team's counter on one slot (tools/membench9.hip, profiles/r4_membench9_handoff_chain.txt).
+    // No wait in here skips a BARRIER when a timeout has been seen: sh[3] can be set by any wave at any time.
+    constexpr int NINSTR = (V == 1) ? E : E / 2;                 // window stores of a thread per round
+    constexpr int PAIR_CNT = NTHR / FFT_PAIR_UNIT * NINSTR;      // sender instructions per seat and round (an image is NTHR x NINSTR stores)
+#if !defined(FFT_EMU)
+    static_assert(!PAIR || (TS == 32 && NR == 32 && E == 16 && RA == 16 && V == 2), "device: store instruction i of a wave goes to seat 8 q + i");
+#endif
+    unsigned* const pair_rcv = p.ctl + TEAM_CTL_PAIR + TEAM_PAIR_WORDS * team + TEAM_PAIR_RCV;  // + 32 * seat
+    unsigned* const pair_landed = p.ctl + TEAM_CTL_PAIR + TEAM_PAIR_WORDS * team + TEAM_PAIR_LANDED;  // + seat
+    unsigned* const pair_pub = p.ctl + TEAM_CTL_PAIR + TEAM_PAIR_WORDS * team + TEAM_PAIR_PUB;
+    const int ap_ = FFT_UNIFORM((tid >> (LOG2RA + LOG2ILN)) & 3);
+    auto pair_dst_seat = [&](int t, int i, int r) __attribute__((always_inline)) -> int {  // the seat store instruction i of round r goes to (`send`)
+        const int g = t & (RA - 1), q = (r - ap_) & 3;
+        int k1;
+        if constexpr (V == 1) k1 = quad_kb<E, RA>(g, i) + MA * q;
+        else if constexpr (GA >= 2) k1 = quad_kb<E, RA>(g, (i / RA) * 2 * RA + (i % RA)) + MA * q;
+        else k1 = (g & ~1) + E * (2 * i + (g & 1)) + MA * q;
+        return k1 >> LOG2NR;
+    };
+    auto pair_signal = [&](int r) __attribute__((always_inline)) {  // call behind FFT_WAIT_VM0: my unit's values of round r are in L2
+        int t = tid0;
+        FFT_OPAQUE(t);
+        if constexpr (FFT_PAIR_UNIT == 1) {
+            FFT_UNROLL
+            for (int i = 0; i < NINSTR; i++) FFT_L2_COUNT_ADD(pair_rcv + 32 * pair_dst_seat(t, i, r));
+        } else {
+            const int lane = t & (FFT_PAIR_UNIT - 1);
+            if (lane < NINSTR) FFT_L2_COUNT_ADD(pair_rcv + 32 * pair_dst_seat(t, lane, r));
+        }
+    };
+    auto pair_guard = [&](int r, unsigned R) __attribute__((always_inline)) {  // the seats I am about to write round R to have pulled round R - 1
+        if (R == 0) return;
+        FFT_LDS_FRESH();
+        if (sh[3]) return;
+        int t = tid0;
+        FFT_OPAQUE(t);
+        const long long tstart = FFT_CLOCK();
+        for (;;) {
+            bool ok = true;
+            if constexpr (FFT_PAIR_UNIT == 1) {
+                FFT_UNROLL
+                for (int i = 0; i < NINSTR; i++) ok = ok && (int)(FFT_L2_FLAG_LOAD(pair_landed + pair_dst_seat(t, i, r)) - R) >= 0;
+            } else {
+#if !defined(FFT_EMU)
+                const fft_u32x8 w8 = fft_scalar_load8_glc(pair_landed + 8 * ((r - ap_) & 3));
+                FFT_UNROLL
+                for (int i = 0; i < 8; i++) ok = ok && (int)(w8[i] - R) >= 0;
+#endif
+            }
+            if (ok) break;
+            if (FFT_CLOCK() - tstart > p.timeout_ticks) {
+                if ((t & (FFT_PAIR_UNIT - 1)) == 0) team_report_timeout(p);
+                sh[3] = 1;
+                break;
+            }
+            FFT_SLEEP();
+        }
+    };
+    // every sender's values of my image of round R are in L2 (the first wave polls, the workgroup waits at the barrier).  learn_it >= 0: the
+    // poll also fetches the team's next transform (`pair_pub`: index + 1, tagged with the iteration it is for) into sh[4]
+    auto pair_wait = [&](unsigned R, int learn_it) __attribute__((always_inline)) {
+        if (tid < FFT_TEAM_POLL_LANES) {
+            FFT_LDS_FRESH();
+            const long long tstart = FFT_CLOCK();
+            bool counted = false;
+            while (!sh[3]) {
+                if (!counted && (int)(FFT_L2_COUNT_POLL(pair_rcv + 32 * s) - (unsigned)PAIR_CNT * (R + 1u)) >= 0) counted = true;
+                if (counted) {
+                    if (learn_it < 0) break;
+                    const unsigned long long both = FFT_L2_LOAD64(pair_pub);
+                    if ((unsigned)(both >> 32) == (unsigned)learn_it + 1u) {
+                        if (tid == 0) sh[4] = (unsigned)both;
+                        break;
+                    }
+                }
+                if (FFT_CLOCK() - tstart > p.timeout_ticks) {
+                    if (tid == 0) team_report_timeout(p);
+                    sh[3] = 1;
+                    break;
+                }
+                FFT_SLEEP();
+                FFT_LDS_FRESH();
+            }
+        }
+        FFT_SYNC_LDS();
     };
 
     // ---- thread coordinates.  Every phase derives them afresh from an opaque copy of the thread id (FFT_OPAQUE): left to
@@ -647,7 +743,8 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
                     for (int k = 0; k < RA; k++) blk[r][i * RA + k] = cmul(blk[r][i * RA + k], w[k]);
                 }
                 if (r == 0) {
-                    if (QUAD_ONE_SLOT) wait_all(G);  // the slot was last read in the previous transform's round 3: long true
+                    if (PAIR) pair_guard(0, 4u * (unsigned)it);  // my seats' images were last read in the previous transform's round 3: long true
+                    else if (QUAD_ONE_SLOT) wait_all(G);  // the slot was last read in the previous transform's round 3: long true
                     send(0);  // drains under block 1's twiddles
                 }
                 if (r == 1) {
@@ -656,15 +753,20 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
                     // arrival is free)
                     if (!QUAD_ONE_SLOT) wait_all(G);  // everybody's image of the previous transform's round 3 has landed: long true
                     FFT_WAIT_VM0();
-                    FFT_SYNC_LDS();
-                    arrive();  // arrival G + 1
+                    if (PAIR) {
+                        pair_signal(0);  // (per wave: no barrier)
+                    } else {
+                        FFT_SYNC_LDS();
+                        arrive();  // arrival G + 1
+                    }
                     ev();
                     if (!QUAD_ONE_SLOT) send(1);  // slot 1 was last read in that round 3
                 }
             }
         }
         ev();
-        wait_all(G + 1);
+        if (PAIR) pair_wait(4u * (unsigned)it, -1);
+        else wait_all(G + 1);
         ev();
         dma_window(0, 0);
         if constexpr (QUAD_ONE_SLOT) {
@@ -674,19 +776,28 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
         // image of round r + 1 is requested at the stage barrier and flies under the second stage.
         FFT_UNROLL
         for (int r = 0; r < 4; r++) {
-            if (r == 1 && p.dynamic && s == 0 && tid == 0) FFT_L2_FLAG_STORE(pub, claimed + 1u);
+            const unsigned R = 4u * (unsigned)it + (unsigned)r;  // (pair protocol: the round's number in the launch)
+            if (r == 1 && p.dynamic && s == 0 && tid == 0) {
+                if (PAIR) FFT_L2_STORE64(pair_pub, claimed + 1u, (unsigned)it + 1u);
+                else FFT_L2_FLAG_STORE(pub, claimed + 1u);
+            }
             // the round's image has landed ... (round 3: the next transform's chunk 0, requested behind it, may still fly: vmcnt counts in issue order)
             if (QUAD_EARLY_CHUNK0 && r == 3 && nxt < p.nb) FFT_WAIT_VM_LE(NCH);
             else FFT_WAIT_VM0();
             FFT_SYNC_LDS();  // ... everybody's of this workgroup
-            arrive();  // L_r
+            if (PAIR) {
+                if (tid == 0) FFT_L2_FLAG_STORE(pair_landed + s, R + 1u);  // L_r: my image may be overwritten
+            } else {
+                arrive();  // L_r
+            }
             ev();
             if (!QUAD_EARLY_CHUNK0 && r == 3) {
                 learn_next();
                 if (nxt < p.nb) dma_chunk(p.in + nxt * n, 0, 0);  // image 0 was last read in round 2
             }
             if (r < 3) {
-                wait_all(G + 2 * r + 2, r == 2);  // the team's
+                if (PAIR) pair_guard(r + 1, R + 1u);  // (per wave: the eight seats it writes to)
+                else wait_all(G + 2 * r + 2, r == 2);  // the team's
                 send(r + 1);
             }
             cpx<T>* img = reinterpret_cast<cpx<T>*>(img_b(r & 1));
@@ -694,8 +805,9 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
             FFT_OPAQUE(t);
             quad_stage1<T, E, RB, LOG2NR, LOG2L2, false>(img, wlB, t & (NR - 1), t >> LOG2NR, false);
             if (r < 3) FFT_WAIT_VM0();  // my round-(r + 1) values are in L2
+            if (PAIR && r < 3) pair_signal(r + 1);
             FFT_SYNC_LDS();
-            if (r < 3) arrive();  // S_(r+1)
+            if (!PAIR && r < 3) arrive();  // S_(r+1)
             FFT_OPAQUE(t);
             const int nr = t >> LOG2NR;
             cpx<T> v[E];
@@ -705,7 +817,8 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
                 dma_chunk(p.in + nxt * n, 1, 1);
             }
             if (r < 3) {
-                wait_all(G + 2 * r + 3);  // everybody's values of round r + 1 are in L2
+                if (PAIR) pair_wait(R + 1u, (r == 2 && p.dynamic) ? it : -1);
+                else wait_all(G + 2 * r + 3);  // everybody's values of round r + 1 are in L2
                 ev();
                 dma_window(0, (r + 1) & 1);
                 if (QUAD_EARLY_CHUNK0 && r == 2) {  // image 0 was read for the last time in front of that wait's barrier

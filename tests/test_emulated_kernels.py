@@ -283,6 +283,41 @@ def test_team_quad_kernel_static_and_dynamic_split_of_the_batch(monkeypatch):
         assert np.array_equal(res[0], res[1])
 
 
+@pytest.mark.parametrize("n,batch,log2seats,n_xcc,threads,lds", [
+    (4096, 9, 2, 2, 64, 8192),    # teams of 4, ragged batch, two "XCDs"
+    (2048, 5, 1, 2, 64, 8192),    # teams of 2 (a seat's rows span two row blocks)
+    (2048, 7, 2, 2, 32, 4096),    # teams of 4, several butterflies per thread in stage 2
+    (1024, 7, 2, 2, 16, 2048),
+])
+def test_team_quad_kernel_pair_protocol(n, batch, log2seats, n_xcc, threads, lds, monkeypatch):
+    """Round 4: the exchange with ONE image per seat in the window and per-seat counters instead of the team's (SLOTS = 3, fft_team_quad.h
+    `pair_guard` / `pair_signal` / `pair_wait`; the device builds it for n = 2^20 in the experiments library only -- correct and slower,
+    profiles/r4_ab_pair_protocol.txt).  Here a sender unit is a host thread: every thread signals and guards for itself.  Static and
+    dynamic split of the batch (the next transform reaches the team through the tagged 8-byte word), both directions, in place; and a
+    member that never arrives ends in a TIMEOUT that the host repairs, with no workgroup stuck at a barrier."""
+    monkeypatch.setenv("FFT_EMU_TEAM_QUAD", "1")
+    monkeypatch.setenv("FFT_EMU_QUAD_SLOTS", "3")
+    x = O.gen_lcg(n, 41, batch).astype(np.complex64)
+    res = []
+    for dyn in ("0", "1"):
+        monkeypatch.setenv("FFT_HIP_TEAM_DYNAMIC", dyn)
+        for d in (-1, 1):
+            for inplace in (False, True):
+                y, info = E.emu_fft_team(x, d, log2seats=log2seats, n_xcc=n_xcc, threads=threads, lds_budget=lds, inplace=inplace)
+                assert info[0] // 100 == 4 and info[6] & 8 and info[5] == 1, (n, dyn, info[5])
+                assert rel(y, oracle(x, d)) < TEAM_TOL[np.complex64], (n, batch, dyn, d, inplace)
+                if d == -1 and not inplace:
+                    res.append(y)
+    assert np.array_equal(res[0], res[1])
+    if n == 4096:
+        monkeypatch.setenv("FFT_EMU_DROP_BLOCK", "1")
+        monkeypatch.setenv("FFT_EMU_TEAM_TIMEOUT_MS", "300")
+        monkeypatch.setenv("FFT_EMU_RECOVER", "1")
+        y, info = E.emu_fft_team(x, -1, log2seats=log2seats, n_xcc=n_xcc, threads=threads, lds_budget=lds)
+        assert info[3] == 1100, "timeout seen, nothing lost: %d" % info[3]
+        assert rel(y, oracle(x, -1)) < TEAM_TOL[np.complex64]
+
+
 @pytest.mark.parametrize("quad", [False, True])
 def test_team_kernel_timeout_is_repaired_on_the_multi_pass_schedule(quad, monkeypatch):
     """VERDICT r2 item 6.  A member of a formed team never arrives (FFT_EMU_DROP_BLOCK leaves right after formation): the team's
