@@ -83,7 +83,7 @@ FFT_DEVICE void quad_st(cpx<T>* p, cpx<T> v) {
 #define QUAD_DEFER_STORES -1  // 2 / 3: each part by a quarter / a half of the waves at a time; 0: all of them when the last round is over; -1: 1 for teams of
 #endif                        // 32 (n = 2^20: +1.3 ... 2 % in four same-box A/Bs), 0 below (+-1 %).  profiles/r4_ab_defer_*.txt
 #ifndef QUAD_ABL  // timing experiments only (tools/ab_quad.sh variants; results invalid): 1 no result stores, 2 no stage barrier in the column
-#define QUAD_ABL 0  // step, 4 none in the row step, 8 no column-step arithmetic, 16 no window stores, 32 no row-step arithmetic, 64 no landing barrier in the column step (with 2: its waves run free of each other)
+#define QUAD_ABL 0  // step, 4 none in the row step, 8 no column-step arithmetic, 16 no window stores, 32 no row-step arithmetic, 64 no landing barrier in the column step (with 2: its waves run free of each other); pair protocol: 128 no guards, 256 no waits for the senders
 #endif
 #ifndef QUAD_FINE_TRACE  // profiling builds only: time stamps inside the column chunks of transform 3 (tools/quad_fine.py)
 #define QUAD_FINE_TRACE 0
@@ -379,6 +379,7 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
     };
     auto pair_guard = [&](int r, unsigned R) __attribute__((always_inline)) {  // the seats I am about to write round R to have pulled round R - 1
         if (R == 0) return;
+        if ((QUAD_ABL & 128) && p.nb >= 0) return;  // (timing experiment: nobody waits for a seat to have pulled its image)
         FFT_LDS_FRESH();
         if (sh[3]) return;
         int t = tid0;
@@ -408,7 +409,7 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
     // every sender's values of my image of round R are in L2 (the first wave polls, the workgroup waits at the barrier).  learn_it >= 0: the
     // poll also fetches the team's next transform (`pair_pub`: index + 1, tagged with the iteration it is for) into sh[4]
     auto pair_wait = [&](unsigned R, int learn_it) __attribute__((always_inline)) {
-        if (tid < FFT_TEAM_POLL_LANES) {
+        if (tid < FFT_TEAM_POLL_LANES && (!(QUAD_ABL & 256) || p.nb < 0)) {  // (256: timing experiment, no seat waits for its senders)
             FFT_LDS_FRESH();
             const long long tstart = FFT_CLOCK();
             bool counted = false;
