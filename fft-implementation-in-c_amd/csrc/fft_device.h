@@ -223,6 +223,12 @@ __device__ __forceinline__ fft_u32x8 fft_scalar_load8_glc(const unsigned* p) {
     asm volatile("s_load_dwordx8 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
     return v;
 }
+typedef unsigned fft_u32x4s __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ fft_u32x4s fft_scalar_load4_glc(const unsigned* p) {
+    fft_u32x4s v;
+    asm volatile("s_load_dwordx4 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+    return v;
+}
 #define FFT_PAIR_UNIT 64
 // the next read of a (non-volatile) LDS word is a real ds_read: volatile accesses through a pointer whose address
 // space the compiler has to infer come out as FLAT loads, which wait on vmcnt as well

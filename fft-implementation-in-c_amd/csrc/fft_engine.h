@@ -380,7 +380,7 @@ class Pow2Plan {
         const long long grid = (long long)team.n_xcc << team.log2seats;
 #define FFT_QUAD_GO(...) rt->launch_coresident(fftk::team_quad_kernel<T, __VA_ARGS__>, grid, team.nthreads, (size_t)team.smem_bytes, tp)
 #if defined(FFT_EMU)
-        const bool pair = getenv("FFT_EMU_QUAD_SLOTS") && atoi(getenv("FFT_EMU_QUAD_SLOTS")) == 3 && team.n_teams <= fftk::TEAM_PAIR_MAX_TEAMS && team.log2TS >= 1;
+        const bool pair = getenv("FFT_EMU_QUAD_SLOTS") && atoi(getenv("FFT_EMU_QUAD_SLOTS")) == 3 && team.log2TS >= 1;
         if (pair && log2n == 12) FFT_QUAD_GO(4, 2, 2, 6, 6, 2, 3);  // the pair protocol (the device's n = 2^20) on teams of 4 and of 2
         else if (pair && log2n == 11 && team.log2TS == 1) FFT_QUAD_GO(4, 2, 1, 6, 5, 1, 3);
         else if (pair && log2n == 11) FFT_QUAD_GO(4, 2, 1, 6, 5, 2, 3);
@@ -395,13 +395,11 @@ class Pow2Plan {
 #else
         if constexpr (SZ == 8) {
             const int slots = rt->team_quad_slots(log2n);
-#if defined(FFT_EXPERIMENTS)
-            if (log2n == 20 && slots == 3 && team.n_teams <= fftk::TEAM_PAIR_MAX_TEAMS) {
-                FFT_QUAD_GO(16, 4, 4, 10, 10, 5, 3);
-                return;
-            }
-#endif
-            if (log2n == 20 && slots == 1) FFT_QUAD_GO(16, 4, 4, 10, 10, 5, 1);
+            if (log2n == 20 && slots == 3) FFT_QUAD_GO(16, 4, 4, 10, 10, 5, 3);
+            else if (log2n == 19 && slots == 3) FFT_QUAD_GO(16, 4, 3, 10, 9, 4, 3);
+            else if (log2n == 18 && slots == 3) FFT_QUAD_GO(16, 3, 3, 9, 9, 3, 3);
+            else if (log2n == 17 && slots == 3) FFT_QUAD_GO(16, 3, 2, 9, 8, 2, 3);
+            else if (log2n == 20 && slots == 1) FFT_QUAD_GO(16, 4, 4, 10, 10, 5, 1);
             else if (log2n == 20) FFT_QUAD_GO(16, 4, 4, 10, 10, 5, 2);
             else if (log2n == 19 && slots == 1) FFT_QUAD_GO(16, 4, 3, 10, 9, 4, 1);
             else if (log2n == 19) FFT_QUAD_GO(16, 4, 3, 10, 9, 4, 2);

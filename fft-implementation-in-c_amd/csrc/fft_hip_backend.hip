@@ -40,8 +40,19 @@ FFT_ROWS_FIXED8_LIST(FFT_EXTERN_FIXED8)
 #undef FFT_EXTERN_FIXED8
 }  // namespace fftk
 
+// the exchange protocol of team_quad_kernel by size (team_quad_slots): 3 = one image per seat + the pair protocol where it measured faster than
+// the team counter (profiles/r4_ab_pair_protocol_sizes.txt: n = 2^20 +1.7 %, 2^19 +3.7 %, 2^18 +-0, 2^17 -1.5 %) -- and it keeps the window in the L2
 #ifndef FFT_QUAD_SLOTS19
-#define FFT_QUAD_SLOTS19 2
+#define FFT_QUAD_SLOTS19 3
+#endif
+#ifndef FFT_QUAD_SLOTS20
+#define FFT_QUAD_SLOTS20 3
+#endif
+#ifndef FFT_QUAD_SLOTS18
+#define FFT_QUAD_SLOTS18 1
+#endif
+#ifndef FFT_QUAD_SLOTS17
+#define FFT_QUAD_SLOTS17 1
 #endif
 #include "fft_engine.h"
 #include "fft_plans_ext.h"
@@ -167,10 +178,11 @@ struct HipRT {
         if (on <= 1) return on == 1;
         return (on >> (log2n - 14)) & 1;
     }
-    // window slots of team_quad_kernel where both protocols are built (n = 2^20, 2^19; the experiments build: FFT_HIP_QUAD_SLOTS=1 / 2)
+    // the exchange protocol of team_quad_kernel where several are built (n = 2^17 ... 2^20): window slots 1 / 2 with the team's arrival counter,
+    // 3 = one image per seat with the pair protocol (the experiments build: FFT_HIP_QUAD_SLOTS=1 / 2 / 3)
     int team_quad_slots(int log2n) {
         static const int v = FFT_EXP_ENV("FFT_HIP_QUAD_SLOTS") ? atoi(FFT_EXP_ENV("FFT_HIP_QUAD_SLOTS")) : 0;
-        return v ? v : (log2n == 20 ? 2 : log2n == 19 ? FFT_QUAD_SLOTS19 : 1);
+        return v ? v : (log2n == 20 ? FFT_QUAD_SLOTS20 : log2n == 19 ? FFT_QUAD_SLOTS19 : log2n == 18 ? FFT_QUAD_SLOTS18 : log2n == 17 ? FFT_QUAD_SLOTS17 : 1);
     }
     // wide_row_kernel (fft_wide_row.h): single-pass n = 8192 and 16384 fp32.  FFT_HIP_WIDE=0 (the experiments build): the two-pass schedule
     bool wide_rows(int elem_bytes, int log2n) {

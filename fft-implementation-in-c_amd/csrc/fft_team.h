@@ -55,17 +55,12 @@ enum {
     TEAM_CTL_COUNT = 32,              // + 32 * xcc : workgroups registered on that XCD (own 128-byte line each)
     TEAM_CTL_FLAGS = 32 + 32 * 16,    // + 32 * team : the team's barrier line, one generation word per member
     TEAM_CTL_MAX_TEAMS = 256,         // 8 XCDs x 32 seats, teams of one
-    // team_quad_kernel's pair protocol (SLOTS = 3), + TEAM_PAIR_WORDS * team, team < TEAM_PAIR_MAX_TEAMS: a line per seat whose first word
-    // counts the sender units whose values of the seat's image are in L2, one line with every seat's "rounds landed" word, one line for
-    // the team's next transform (8 bytes: index + 1, the iteration it is for)
+    // team_quad_kernel's pair protocol (SLOTS = 3), + 32 * (2 TS + 1) * team for teams of TS seats: a line per seat whose first word counts
+    // the sender units whose values of the seat's image are in L2; every seat's "rounds landed" word, one copy of that line PER READING SEAT
+    // (256 waves polling one line of the L2 made a poll 2.3 us: profiles/r4_ab_pair_protocol_polls.txt); one line for the team's next
+    // transform (8 bytes: index + 1, the iteration it is for).  3 lines per workgroup cover every team size.
     TEAM_CTL_PAIR = 32 + 32 * 16 + 32 * TEAM_CTL_MAX_TEAMS,
-    TEAM_PAIR_RCV = 0, TEAM_PAIR_LANDED = 32 * 32, TEAM_PAIR_PUB = 32 * 32 + 32, TEAM_PAIR_WORDS = 32 * 32 + 64,
-    TEAM_PAIR_MAX_TEAMS = 16,
-#if defined(FFT_EXPERIMENTS) || defined(FFT_EMU)  // (the product library has no kernel with that protocol: measured slower, fft_team_quad.h)
-    TEAM_CTL_WORDS = TEAM_CTL_PAIR + TEAM_PAIR_WORDS * TEAM_PAIR_MAX_TEAMS
-#else
-    TEAM_CTL_WORDS = TEAM_CTL_PAIR
-#endif
+    TEAM_CTL_WORDS = TEAM_CTL_PAIR + 32 * 3 * TEAM_CTL_MAX_TEAMS
 };
 // sticky words: NOT zeroed per launch (a TIMEOUT of any queued execute must survive the next execute's memset of the
 // control block); the host reads and clears them when it syncs (team_status_of)

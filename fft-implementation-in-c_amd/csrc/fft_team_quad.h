@@ -83,7 +83,7 @@ FFT_DEVICE void quad_st(cpx<T>* p, cpx<T> v) {
 #define QUAD_DEFER_STORES -1  // 2 / 3: each part by a quarter / a half of the waves at a time; 0: all of them when the last round is over; -1: 1 for teams of
 #endif                        // 32 (n = 2^20: +1.3 ... 2 % in four same-box A/Bs), 0 below (+-1 %).  profiles/r4_ab_defer_*.txt
 #ifndef QUAD_ABL  // timing experiments only (tools/ab_quad.sh variants; results invalid): 1 no result stores, 2 no stage barrier in the column
-#define QUAD_ABL 0  // step, 4 none in the row step, 8 no column-step arithmetic, 16 no window stores, 32 no row-step arithmetic, 64 no landing barrier in the column step (with 2: its waves run free of each other); pair protocol: 128 no guards, 256 no waits for the senders
+#define QUAD_ABL 0  // step, 4 none in the row step, 8 no column-step arithmetic, 16 no window stores, 32 no row-step arithmetic, 64 no landing barrier in the column step (with 2: its waves run free of each other); pair protocol: 128 no guards, 256 no waits for the senders, 512 a guard is ONE poll
 #endif
 #ifndef QUAD_FINE_TRACE  // profiling builds only: time stamps inside the column chunks of transform 3 (tools/quad_fine.py)
 #define QUAD_FINE_TRACE 0
@@ -343,20 +343,24 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
     //   * a sender UNIT (a wave on the device: its store instruction i goes to ONE seat) tells each seat it has written to, as soon as ITS
     //     stores are complete -- no workgroup barrier --: one atomic add per store instruction on the seat's counter `rcv`;
     //   * a seat pulls its image of round R when its own counter says that all (R + 1) x CNT instructions are in, and says so in its word of
-    //     the team's `landed` line (a plain store of R + 1);
+    //     the team's `landed` line (plain stores of R + 1 into a copy of that line for every seat: one store instruction of TS lanes);
     //   * a unit writes round R into a seat's image when that seat's word says R (rounds < R have landed): it reads the words of the seats
-    //     it is about to write to -- on the device the eight adjacent words of its quarter of the team in ONE scalar load.
+    //     it is about to write to in its own seat's copy -- on the device the eight adjacent words of its quarter of the team in ONE scalar
+    //     load.
     // A seat waits for its own 64 sender waves and a wave for its own 8 receivers, never for the slowest of the whole team: the store -> pull
     // chain is 3.6 us against 5.4 with the team's counter on one slot (tools/membench9.hip, profiles/r4_membench9_handoff_chain.txt).
     // No wait in here skips a BARRIER when a timeout has been seen: sh[3] can be set by any wave at any time.
     constexpr int NINSTR = (V == 1) ? E : E / 2;                 // window stores of a thread per round
     constexpr int PAIR_CNT = NTHR / FFT_PAIR_UNIT * NINSTR;      // sender instructions per seat and round (an image is NTHR x NINSTR stores)
+    // device: store instruction i of a wave goes to ONE seat, and a wave's seats are the SPQ = TS / 4 adjacent ones of block q = (r - ap) mod 4
+    // of the rows (k1 = kb + MA q, kb < MA = SPQ NR): true of every device shape with TS >= 4 (a wave = RA lanes g x ILN columns of one class)
+    constexpr int SPQ = TS >= 4 ? TS / 4 : 1;
 #if !defined(FFT_EMU)
-    static_assert(!PAIR || (TS == 32 && NR == 32 && E == 16 && RA == 16 && V == 2), "device: store instruction i of a wave goes to seat 8 q + i");
+    static_assert(!PAIR || (TS >= 4 && MA == SPQ * NR && NINSTR == 8 && NTHR % 64 == 0), "pair protocol: teams of at least 4, eight window stores per thread and round");
 #endif
-    unsigned* const pair_rcv = p.ctl + TEAM_CTL_PAIR + TEAM_PAIR_WORDS * team + TEAM_PAIR_RCV;  // + 32 * seat
-    unsigned* const pair_landed = p.ctl + TEAM_CTL_PAIR + TEAM_PAIR_WORDS * team + TEAM_PAIR_LANDED;  // + seat
-    unsigned* const pair_pub = p.ctl + TEAM_CTL_PAIR + TEAM_PAIR_WORDS * team + TEAM_PAIR_PUB;
+    unsigned* const pair_rcv = p.ctl + TEAM_CTL_PAIR + 32 * (2 * TS + 1) * team;  // + 32 * seat
+    unsigned* const pair_landed = pair_rcv + 32 * TS;                            // + 32 * reading seat + seat
+    unsigned* const pair_pub = pair_rcv + 64 * TS;
     const int ap_ = FFT_UNIFORM((tid >> (LOG2RA + LOG2ILN)) & 3);
     auto pair_dst_seat = [&](int t, int i, int r) __attribute__((always_inline)) -> int {  // the seat store instruction i of round r goes to (`send`)
         const int g = t & (RA - 1), q = (r - ap_) & 3;
@@ -389,15 +393,28 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
             bool ok = true;
             if constexpr (FFT_PAIR_UNIT == 1) {
                 FFT_UNROLL
-                for (int i = 0; i < NINSTR; i++) ok = ok && (int)(FFT_L2_FLAG_LOAD(pair_landed + pair_dst_seat(t, i, r)) - R) >= 0;
+                for (int i = 0; i < NINSTR; i++) ok = ok && (int)(FFT_L2_FLAG_LOAD(pair_landed + 32 * s + pair_dst_seat(t, i, r)) - R) >= 0;
             } else {
 #if !defined(FFT_EMU)
-                const fft_u32x8 w8 = fft_scalar_load8_glc(pair_landed + 8 * ((r - ap_) & 3));
-                FFT_UNROLL
-                for (int i = 0; i < 8; i++) ok = ok && (int)(w8[i] - R) >= 0;
+                const unsigned* const mine = pair_landed + 32 * s + SPQ * ((r - ap_) & 3);
+                if constexpr (SPQ == 8) {
+                    const fft_u32x8 w8 = fft_scalar_load8_glc(mine);
+                    FFT_UNROLL
+                    for (int i = 0; i < 8; i++) ok = ok && (int)(w8[i] - R) >= 0;
+                } else if constexpr (SPQ == 4) {
+                    const fft_u32x4s w4 = fft_scalar_load4_glc(mine);
+                    FFT_UNROLL
+                    for (int i = 0; i < 4; i++) ok = ok && (int)(w4[i] - R) >= 0;
+                } else if constexpr (SPQ == 2) {
+                    const unsigned long long w2 = fft_scalar_load2_glc(mine);
+                    ok = (int)((unsigned)w2 - R) >= 0 && (int)((unsigned)(w2 >> 32) - R) >= 0;
+                } else {
+                    ok = (int)(fft_scalar_load_glc(mine) - R) >= 0;
+                }
 #endif
             }
             if (ok) break;
+            if ((QUAD_ABL & 512) && p.nb >= 0) break;  // (timing experiment: one poll, whatever it says)
             if (FFT_CLOCK() - tstart > p.timeout_ticks) {
                 if ((t & (FFT_PAIR_UNIT - 1)) == 0) team_report_timeout(p);
                 sh[3] = 1;
@@ -787,7 +804,7 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
             else FFT_WAIT_VM0();
             FFT_SYNC_LDS();  // ... everybody's of this workgroup
             if (PAIR) {
-                if (tid == 0) FFT_L2_FLAG_STORE(pair_landed + s, R + 1u);  // L_r: my image may be overwritten
+                if (tid < TS) FFT_L2_FLAG_STORE(pair_landed + 32 * tid + s, R + 1u);  // L_r: my image may be overwritten (a copy for every seat)
             } else {
                 arrive();  // L_r
             }
@@ -797,7 +814,9 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
                 if (nxt < p.nb) dma_chunk(p.in + nxt * n, 0, 0);  // image 0 was last read in round 2
             }
             if (r < 3) {
-                if (PAIR) pair_guard(r + 1, R + 1u);  // (per wave: the eight seats it writes to)
+                // (pair protocol, these three hand-offs one step later each -- guard and values behind the stage barrier, signal behind the
+                // stage-2 reads, image request behind the stage-2 butterflies --: 2.58 against 2.49 ms, profiles/r4_ab_pair_protocol_landed_copies.txt)
+                if (PAIR) pair_guard(r + 1, R + 1u);  // (per wave: the seats it writes to)
                 else wait_all(G + 2 * r + 2, r == 2);  // the team's
                 send(r + 1);
             }

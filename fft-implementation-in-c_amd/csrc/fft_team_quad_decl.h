@@ -18,22 +18,18 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
 
 #if !defined(FFT_EMU)
 // <T, E, log2 RA, log2 RB, log2 L1, log2 L2, log2 TS, window slots>; the list of fft_team_quad.hip
-#if defined(FFT_EXPERIMENTS)
-// n = 2^20 with ONE image per seat and the pair protocol (SLOTS = 3, FFT_HIP_QUAD_SLOTS=3): correct, 148 - 151 against 213 Gpoint/s
-// (profiles/r4_ab_pair_protocol.txt) -- the experiments library only
-#define FFT_QUAD_INSTANCES_EXP(X) X(float, 16, 4, 4, 10, 10, 5, 3)
-#else
-#define FFT_QUAD_INSTANCES_EXP(X)
-#endif
 #define FFT_QUAD_INSTANCES(X)                                                                                         \
     X(float, 16, 4, 4, 10, 10, 5, 2) /* n = 2^20: 1024 x 1024, teams of 32 (a whole XCD), two window slots */          \
     X(float, 16, 4, 4, 10, 10, 5, 1) /* ... with one (experiments: FFT_HIP_QUAD_SLOTS=1; traffic 1.08 x, but -20 %) */ \
-    FFT_QUAD_INSTANCES_EXP(X)                                                                                         \
+    X(float, 16, 4, 4, 10, 10, 5, 3) /* ... ONE image per seat and the pair protocol (per-seat counters, no team-wide wait) */ \
     X(float, 16, 4, 3, 10, 9, 4, 2)  /* n = 2^19: 1024 x 512, teams of 16 */                                           \
     X(float, 16, 4, 3, 10, 9, 4, 1)                                                                                    \
+    X(float, 16, 4, 3, 10, 9, 4, 3)                                                                                    \
     X(float, 16, 3, 3, 9, 9, 3, 1)   /* n = 2^18: 512 x 512, teams of 8, one window slot */                            \
     X(float, 16, 3, 3, 9, 9, 3, 2)   /* ... two (experiments) */                                                       \
+    X(float, 16, 3, 3, 9, 9, 3, 3)   /* ... pair protocol */                                                           \
     X(float, 16, 3, 2, 9, 8, 2, 1)   /* n = 2^17: 512 x 256, teams of 4 */                                             \
+    X(float, 16, 3, 2, 9, 8, 2, 3)                                                                                     \
     X(float, 16, 2, 2, 8, 8, 1, 1)   /* n = 2^16: 256 x 256, teams of 2 */                                             \
     X(float, 16, 2, 1, 8, 7, 0, 1)   /* n = 2^15: 256 x 128, one CU per transform */                                   \
     X(double, 8, 3, 1, 8, 6, 0, 1)   /* fp64 n = 2^14: 256 x 64, one CU per transform */                               \
