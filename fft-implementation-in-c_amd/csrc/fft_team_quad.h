@@ -16,7 +16,8 @@
 //   combine: radix-4 butterflies over a, thread-local, then the inter-step twiddle W_n^(k1 j2): the thread now holds
 //       X[k1][j2] for 4 E rows k1 of ONE column j2;
 //   exchange + row step, round r = 0..3: every seat writes a quarter of its values into the team's window in the
-//       XCD's L2 (2 slots of TS x 64 KiB, rewritten every other round -- or one, see SLOTS), one team-wide arrival, every
+//       XCD's L2 (2 slots of TS x 64 KiB, rewritten every other round -- or one, see SLOTS), one team-wide arrival (or,
+//       SLOTS = 3, per-seat counters and no team-wide wait at all: the pair protocol, n = 2^20 and 2^19), every
 //       seat pulls its 64 KiB image of the round -- the samples j2 = 4 b' + a' of ONE residue class a' for each of its NR rows --
 //       into LDS (sc1 LDS-DMA), runs the length-MB transforms (MB = E RB) and keeps the results;
 //   final: radix-4 over the classes, thread-local; all 4 E results of a thread go out as whole NR-row segments.
@@ -234,7 +235,8 @@ FFT_DEVICE void quad_twiddle_kb(cpx<T> (&x)[E], const cpx<T> (&v)[E], const cpx<
 // of the window reads miss (memory-side traffic 1.58 x the algorithmic bytes, profiles/r3_pmc_oneslot.txt).  1 (2 MiB per XCD): the
 // slot is rewritten in L2 (traffic 1.08 x), at the price of strict alternation -- write, everybody reads, write -- with eight
 // arrivals per transform and two team waits per round that sit on the critical path.  Measured (profiles/r3_ab_quad.txt): teams of 2
-// (n = 2^16) +6.5 % with one slot, teams of 8 (2^18) +-1 %, teams of 32 (2^20) -20 %.
+// (n = 2^16) +6.5 % with one slot, teams of 8 (2^18) +-1 %, teams of 32 (2^20) -20 %.  3 (round 4): one slot's window and schedule with the
+// pair protocol instead of the team's counter (`pair_guard` below): teams of 32 +1.7 %, of 16 +3.7 % over two slots, and the traffic of one.
 template <typename T, int E, int LOG2RA, int LOG2RB, int LOG2L1, int LOG2L2, int LOG2TS, int SLOTS>
 FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamParams<T> p) {
     constexpr bool PAIR = SLOTS == 3;  // one image per seat in the window, per-seat counters instead of the team's (see `pair_guard`)
@@ -349,6 +351,8 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
     //     load.
     // A seat waits for its own 64 sender waves and a wave for its own 8 receivers, never for the slowest of the whole team: the store -> pull
     // chain is 3.6 us against 5.4 with the team's counter on one slot (tools/membench9.hip, profiles/r4_membench9_handoff_chain.txt).
+    // The `landed` line exists once PER READING SEAT: with one line for the team, 256 waves of an XCD polled the line 32 seats store into and
+    // every poll took 2.3 us (3.6 instead of 2.49 ms per launch, profiles/r4_ab_pair_protocol_polls.txt).
     // No wait in here skips a BARRIER when a timeout has been seen: sh[3] can be set by any wave at any time.
     constexpr int NINSTR = (V == 1) ? E : E / 2;                 // window stores of a thread per round
     constexpr int PAIR_CNT = NTHR / FFT_PAIR_UNIT * NINSTR;      // sender instructions per seat and round (an image is NTHR x NINSTR stores)

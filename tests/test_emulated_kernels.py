@@ -291,8 +291,7 @@ def test_team_quad_kernel_static_and_dynamic_split_of_the_batch(monkeypatch):
 ])
 def test_team_quad_kernel_pair_protocol(n, batch, log2seats, n_xcc, threads, lds, monkeypatch):
     """Round 4: the exchange with ONE image per seat in the window and per-seat counters instead of the team's (SLOTS = 3, fft_team_quad.h
-    `pair_guard` / `pair_signal` / `pair_wait`; the device builds it for n = 2^20 in the experiments library only -- correct and slower,
-    profiles/r4_ab_pair_protocol.txt).  Here a sender unit is a host thread: every thread signals and guards for itself.  Static and
+    `pair_guard` / `pair_signal` / `pair_wait`; the device's schedule at n = 2^20 and 2^19, profiles/r4_ab_pair_protocol_sizes.txt).  Here a sender unit is a host thread: every thread signals and guards for itself.  Static and
     dynamic split of the batch (the next transform reaches the team through the tagged 8-byte word), both directions, in place; and a
     member that never arrives ends in a TIMEOUT that the host repairs, with no workgroup stuck at a barrier."""
     monkeypatch.setenv("FFT_EMU_TEAM_QUAD", "1")
