@@ -83,6 +83,9 @@ FFT_DEVICE void quad_st(cpx<T>* p, cpx<T> v) {
 #ifndef QUAD_DEFER_STORES  // 1: a transform's result stores go out in four parts from the column step of the team's NEXT transform (see `final_part`);
 #define QUAD_DEFER_STORES -1  // 2 / 3: each part by a quarter / a half of the waves at a time; 0: all of them when the last round is over; -1: 1 for teams of
 #endif                        // 32 (n = 2^20: +1.3 ... 2 % in four same-box A/Bs), 0 below (+-1 %).  profiles/r4_ab_defer_*.txt
+#ifndef QUAD_COL_AHEAD  // 1 (with the deferred result stores): column chunk a + 2 is requested as soon as chunk a's image is free (behind its stage-2
+#define QUAD_COL_AHEAD 1  // reads), not when chunk a + 1 has landed: two chunks in flight per CU during most of the column step (12.3 instead of
+#endif                    // 13.5 us; +0.9 % at n = 2^20 in three same-box pairs, profiles/r4_ab_column_ahead.txt)
 #ifndef QUAD_ABL  // timing experiments only (tools/ab_quad.sh variants; results invalid): 1 no result stores, 2 no stage barrier in the column
 #define QUAD_ABL 0  // step, 4 none in the row step, 8 no column-step arithmetic, 16 no window stores, 32 no row-step arithmetic, 64 no landing barrier in the column step (with 2: its waves run free of each other); pair protocol: 128 no guards, 256 no waits for the senders, 512 a guard is ONE poll
 #endif
@@ -612,7 +615,14 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
             // my pieces of the chunk have landed ... everybody's have; the other image was last read before this barrier.
             // What may still be in flight behind chunk 0's DMA are the previous transform's 4 E / 2 result stores (vmcnt counts
             // in issue order)
-            if (DEFER) {
+            constexpr bool AHEAD = DEFER == 1 && QUAD_COL_AHEAD;
+            static_assert(!AHEAD || (QUAD_EARLY_CHUNK0 && QUAD_EARLY_CHUNK1), "the counted waits assume chunks 0 and 1 of a team's next transform are requested in rounds 2 and 3");
+            if (AHEAD) {
+                // in issue order: chunk a, [part a - 1's stores], chunk a + 1 -- the eight youngest requests may still fly, except in front of the
+                // last chunk and of the launch's first
+                if (a == 3 || (a == 0 && it == 0)) FFT_WAIT_VM0();
+                else FFT_WAIT_VM_LE(NCH);
+            } else if (DEFER) {
                 // (chunk a's pieces are the youngest thing this thread has issued: its request follows part a - 1's stores -- that order measured
                 // faster than the request first --, so the wait for the pieces is a wait for everything)
                 FFT_WAIT_VM0();
@@ -638,7 +648,7 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
             // counts the previous transform's result stores (vmcnt counts in issue order: in front of it the claim would make its wave
             // wait for the first of those stores, and the team for that wave: -10 % at n = 2^20)
             if (a == 3 && p.dynamic && s == 0 && tid == 0) claimed = FFT_ATOMIC_ADD_AGENT_RELAXED(claim, 1u) + (unsigned)n_teams;
-            if (a + 1 < 4 && !(QUAD_EARLY_CHUNK1 && a == 0 && it > 0)) dma_chunk(inb, a + 1, (a + 1) & 1);
+            if (a + 1 < 4 && !(QUAD_EARLY_CHUNK1 && a == 0 && it > 0) && !(AHEAD && a >= 1)) dma_chunk(inb, a + 1, (a + 1) & 1);
             cpx<T>* img = reinterpret_cast<cpx<T>*>(img_b(a & 1));
             int t = tid0;
             FFT_OPAQUE(t);
@@ -674,6 +684,10 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
             if (!(QUAD_ABL & 8) || p.nb < 0) {
                 quad_stage2_read<T, E, LOG2NC>(v, img, quad_rot<RA, NC>(c2, g), g);
                 if (DEFER == 2 && drain && sgrp == 3) final_part(a, out_prev);
+                if (AHEAD && a + 2 < 4) {
+                    FFT_SYNC_LDS();  // everybody has read this image for the last time
+                    dma_chunk(inb, a + 2, a & 1);
+                }
                 quad_stage2_dft<T, E, RA>(v);
             } else {
                 FFT_UNROLL
@@ -845,7 +859,7 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
                 else wait_all(G + 2 * r + 3);  // everybody's values of round r + 1 are in L2
                 ev();
                 dma_window(0, (r + 1) & 1);
-                if (QUAD_EARLY_CHUNK0 && r == 2) {  // image 0 was read for the last time in front of that wait's barrier
+                if (QUAD_EARLY_CHUNK0 && r == 2) {  // image 0 was read for the last time in front of that wait's barrier (behind this round's butterflies or twiddles instead: +-0.3 %)
                     learn_next();
                     if (nxt < p.nb) dma_chunk(p.in + nxt * n, 0, 0);
                 }
