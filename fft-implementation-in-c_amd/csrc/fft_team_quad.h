@@ -834,6 +834,7 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
             if (r < 3) {
                 // (pair protocol, these three hand-offs one step later each -- guard and values behind the stage barrier, signal behind the
                 // stage-2 reads, image request behind the stage-2 butterflies --: 2.58 against 2.49 ms, profiles/r4_ab_pair_protocol_landed_copies.txt)
+                // (guard and values from INSIDE stage 1, behind the issue of its LDS reads: +-0, profiles/r4_ab_guard_in_stage.txt)
                 if (PAIR) pair_guard(r + 1, R + 1u);  // (per wave: the seats it writes to)
                 else wait_all(G + 2 * r + 2, r == 2);  // the team's
                 send(r + 1);
