@@ -83,9 +83,9 @@ FFT_DEVICE void quad_st(cpx<T>* p, cpx<T> v) {
 #ifndef QUAD_DEFER_STORES  // 1: a transform's result stores go out in four parts from the column step of the team's NEXT transform (see `final_part`);
 #define QUAD_DEFER_STORES -1  // 2 / 3: each part by a quarter / a half of the waves at a time; 0: all of them when the last round is over; -1: 1 for teams of
 #endif                        // 32 (n = 2^20: +1.3 ... 2 % in four same-box A/Bs), 0 below (+-1 %).  profiles/r4_ab_defer_*.txt
-#ifndef QUAD_COL_AHEAD  // 1 (with the deferred result stores): column chunk a + 2 is requested as soon as chunk a's image is free (behind its stage-2
+#ifndef QUAD_COL_AHEAD  // 1 (teams of 32 and the fp64 shapes): column chunk a + 2 is requested as soon as chunk a's image is free (behind its stage-2
 #define QUAD_COL_AHEAD 1  // reads), not when chunk a + 1 has landed: two chunks in flight per CU during most of the column step (12.3 instead of
-#endif                    // 13.5 us; +0.9 % at n = 2^20 in three same-box pairs, profiles/r4_ab_column_ahead.txt)
+#endif                    // 13.5 us; +0.9 % at n = 2^20 in three same-box pairs, profiles/r4_ab_column_ahead.txt); 2: every shape
 #ifndef QUAD_ABL  // timing experiments only (tools/ab_quad.sh variants; results invalid): 1 no result stores, 2 no stage barrier in the column
 #define QUAD_ABL 0  // step, 4 none in the row step, 8 no column-step arithmetic, 16 no window stores, 32 no row-step arithmetic, 64 no landing barrier in the column step (with 2: its waves run free of each other); pair protocol: 128 no guards, 256 no waits for the senders, 512 a guard is ONE poll
 #endif
@@ -615,13 +615,28 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
             // my pieces of the chunk have landed ... everybody's have; the other image was last read before this barrier.
             // What may still be in flight behind chunk 0's DMA are the previous transform's 4 E / 2 result stores (vmcnt counts
             // in issue order)
-            constexpr bool AHEAD = DEFER == 1 && QUAD_COL_AHEAD;
+            // (where: teams of 32 with the deferred stores +0.9 %; fp64 n = 2^14 ... 2^16 +7 / +4 / +4 %; the other fp32 shapes +1 ... -1.3 %: not
+            // there -- profiles/r4_ab_column_ahead.txt, r4_ab_column_ahead_all_shapes.txt; QUAD_COL_AHEAD = 2: every shape)
+            constexpr bool AHEAD = (DEFER == 1 || (DEFER == 0 && (sizeof(T) == 8 || QUAD_COL_AHEAD >= 2))) && QUAD_COL_AHEAD;
             static_assert(!AHEAD || (QUAD_EARLY_CHUNK0 && QUAD_EARLY_CHUNK1), "the counted waits assume chunks 0 and 1 of a team's next transform are requested in rounds 2 and 3");
-            if (AHEAD) {
+            if (AHEAD && DEFER) {
                 // in issue order: chunk a, [part a - 1's stores], chunk a + 1 -- the eight youngest requests may still fly, except in front of the
                 // last chunk and of the launch's first
                 if (a == 3 || (a == 0 && it == 0)) FFT_WAIT_VM0();
                 else FFT_WAIT_VM_LE(NCH);
+            } else if (AHEAD) {
+                // results not deferred; in issue order: chunk 0, chunk 1, the previous transform's 4 E / V result stores, chunk 2, chunk 3
+                if (a == 0) {
+                    if (it > 0) FFT_WAIT_VM_LE(4 * E / V + NCH);
+                    else FFT_WAIT_VM0();
+                } else if (a == 1) {
+                    if (it > 0) FFT_WAIT_VM_LE(4 * E / V + NCH);  // (chunk 1 is older than those stores)
+                    else FFT_WAIT_VM_LE(NCH);
+                } else if (a == 2) {
+                    FFT_WAIT_VM_LE(NCH);
+                } else {
+                    FFT_WAIT_VM0();
+                }
             } else if (DEFER) {
                 // (chunk a's pieces are the youngest thing this thread has issued: its request follows part a - 1's stores -- that order measured
                 // faster than the request first --, so the wait for the pieces is a wait for everything)
