@@ -83,6 +83,9 @@ FFT_DEVICE void quad_st(cpx<T>* p, cpx<T> v) {
 #ifndef QUAD_DEFER_STORES  // 1: a transform's result stores go out in four parts from the column step of the team's NEXT transform (see `final_part`);
 #define QUAD_DEFER_STORES -1  // 2 / 3: each part by a quarter / a half of the waves at a time; 0: all of them when the last round is over; -1: 1 for teams of
 #endif                        // 32 (n = 2^20: +1.3 ... 2 % in four same-box A/Bs), 0 below (+-1 %).  profiles/r4_ab_defer_*.txt
+#ifndef QUAD_PAIR_SIGNAL_AT  // pair protocol: where a wave tells the seats it has written to -- 0: behind stage 1 of the round, 1 / 2 / 3: from inside that stage
+#define QUAD_PAIR_SIGNAL_AT 2  // (reads in / behind the butterflies / behind the twiddles).  2: +0.7 % at n = 2^20, +1.2 % at 2^19; 1 and 3: +-0
+#endif                        // (profiles/r4_ab_pair_signal_point.txt)
 #ifndef QUAD_COL_AHEAD  // 1 (teams of 32 and the fp64 shapes): column chunk a + 2 is requested as soon as chunk a's image is free (behind its stage-2
 #define QUAD_COL_AHEAD 1  // reads), not when chunk a + 1 has landed: two chunks in flight per CU during most of the column step (12.3 instead of
 #endif                    // 13.5 us; +0.9 % at n = 2^20 in three same-box pairs, profiles/r4_ab_column_ahead.txt); 2: every shape
@@ -857,9 +860,20 @@ FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamPar
             cpx<T>* img = reinterpret_cast<cpx<T>*>(img_b(r & 1));
             int t = tid0;
             FFT_OPAQUE(t);
-            quad_stage1<T, E, RB, LOG2NR, LOG2L2, false>(img, wlB, t & (NR - 1), t >> LOG2NR, false);
-            if (r < 3) FFT_WAIT_VM0();  // my round-(r + 1) values are in L2
-            if (PAIR && r < 3) pair_signal(r + 1);
+            // QUAD_PAIR_SIGNAL_AT (pair protocol): the wave's signal from inside stage 1 -- 1: when its LDS reads are in, 2: behind its butterflies, 3: behind
+            // its twiddles -- instead of behind its LDS writes
+            constexpr int SIG_AT = PAIR ? QUAD_PAIR_SIGNAL_AT : 0;
+            int n_mark_s = 0;
+            auto signal_mark = [&](int) __attribute__((always_inline)) {
+                if (SIG_AT && r < 3 && n_mark_s == SIG_AT - 1) {
+                    FFT_WAIT_VM0();
+                    pair_signal(r + 1);
+                }
+                n_mark_s++;
+            };
+            quad_stage1<T, E, RB, LOG2NR, LOG2L2, false>(img, wlB, t & (NR - 1), t >> LOG2NR, false, signal_mark);
+            if (r < 3 && !SIG_AT) FFT_WAIT_VM0();  // my round-(r + 1) values are in L2
+            if (PAIR && r < 3 && !SIG_AT) pair_signal(r + 1);
             FFT_SYNC_LDS();
             if (!PAIR && r < 3) arrive();  // S_(r+1)
             FFT_OPAQUE(t);
