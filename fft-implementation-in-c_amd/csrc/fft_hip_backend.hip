@@ -41,15 +41,16 @@ FFT_ROWS_FIXED8_LIST(FFT_EXTERN_FIXED8)
 }  // namespace fftk
 
 // the exchange protocol of team_quad_kernel by size (team_quad_slots): 3 = one image per seat + the pair protocol where it measured faster than
-// the team counter (profiles/r4_ab_pair_protocol_sizes.txt: n = 2^20 +1.7 %, 2^19 +3.7 %, 2^18 +-0, 2^17 -1.5 %) -- and it keeps the window in the L2
+// the team counter (profiles/r4_ab_pair_protocol_sizes.txt: n = 2^20 +1.7 %, 2^19 +3.7 %, 2^18 +-0, 2^17 -1.5 % with its first schedule) -- and it keeps the
+// window in the L2
 #ifndef FFT_QUAD_SLOTS19
 #define FFT_QUAD_SLOTS19 3
 #endif
 #ifndef FFT_QUAD_SLOTS20
 #define FFT_QUAD_SLOTS20 3
 #endif
-#ifndef FFT_QUAD_SLOTS18
-#define FFT_QUAD_SLOTS18 1
+#ifndef FFT_QUAD_SLOTS18  // (with the protocol's final schedule: 1.115 - 1.146 against 1.144 - 1.175 ms in four same-box pairs, profiles/r4_ab_pair_protocol_256k_128k.txt;
+#define FFT_QUAD_SLOTS18 3  // n = 2^17: +-0.3 %, stays on the team counter)
 #endif
 #ifndef FFT_QUAD_SLOTS17
 #define FFT_QUAD_SLOTS17 1
