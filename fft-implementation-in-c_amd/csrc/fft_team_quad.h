@@ -82,7 +82,8 @@ FFT_DEVICE void quad_st(cpx<T>* p, cpx<T> v) {
 #endif
 #ifndef QUAD_DEFER_STORES  // 1: a transform's result stores go out in four parts from the column step of the team's NEXT transform (see `final_part`);
 #define QUAD_DEFER_STORES -1  // 2 / 3: each part by a quarter / a half of the waves at a time; 0: all of them when the last round is over; -1: 1 for teams of
-#endif                        // 32 (n = 2^20: +1.3 ... 2 % in four same-box A/Bs), 0 below (+-1 %).  profiles/r4_ab_defer_*.txt
+#endif                        // 32 and 16 (n = 2^20: +1.3 ... 2 % on two slots, +5 % on the pair protocol; 2^19 on the pair protocol +1.1 %), 0 below (2^18: -3 %, 2^17 and
+                              // 2^16 +-0.5 %).  profiles/r4_ab_defer_*.txt, r4_ab_pair_protocol_knobs.txt, r4_ab_defer_small_teams.txt
 #ifndef QUAD_PAIR_SIGNAL_AT  // pair protocol: where a wave tells the seats it has written to -- 0: behind stage 1 of the round, 1 / 2 / 3: from inside that stage
 #define QUAD_PAIR_SIGNAL_AT 2  // (reads in / behind the butterflies / behind the twiddles).  2: +0.7 % at n = 2^20, +1.2 % at 2^19; 1 and 3: +-0
 #endif                        // (profiles/r4_ab_pair_signal_point.txt)
@@ -247,7 +248,7 @@ template <typename T, int E, int LOG2RA, int LOG2RB, int LOG2L1, int LOG2L2, int
 FFT_KERNEL void FFT_QUAD_BOUNDS(LOG2RA, LOG2L2, LOG2TS) team_quad_kernel(TeamParams<T> p) {
     constexpr bool PAIR = SLOTS == 3;  // one image per seat in the window, per-seat counters instead of the team's (see `pair_guard`)
     constexpr bool QUAD_ONE_SLOT = SLOTS == 1 || PAIR;
-    constexpr int DEFER = QUAD_DEFER_STORES >= 0 ? QUAD_DEFER_STORES : ((LOG2TS >= 5 && sizeof(T) == 4) ? 1 : 0);
+    constexpr int DEFER = QUAD_DEFER_STORES >= 0 ? QUAD_DEFER_STORES : ((LOG2TS >= 4 && sizeof(T) == 4) ? 1 : 0);
     static_assert(SLOTS == 1 || SLOTS == 2 || SLOTS == 3, "one or two window slots, or one with the pair protocol");
     constexpr int V = vec16<T>::V;  // values per 16-byte access: 2 (fp32: the values of two adjacent rows travel together), 1 (fp64)
     using S = QuadShape<E, LOG2RA, LOG2RB, LOG2L1, LOG2L2, LOG2TS>;
