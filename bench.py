@@ -530,7 +530,7 @@ def main():
         team_cus = max(1, n // (info.team_tiles * tile_points))
         team_src = {1: "csrc/fft_team.h team_fft_kernel", 2: "csrc/fft_team_defer.h team_defer_kernel",
                     3: "csrc/fft_team_quad.h team_quad_kernel (256-byte row segments, both steps decimated in time by 4, the "
-                       "exchange between them in four rounds through the XCD's L2)"}.get(info.team_kernel, "team kernel")
+                       "exchange between them in four rounds through the XCD's L2; n = 2^18 ... 2^20: one image per seat in the window, per-seat counters)"}.get(info.team_kernel, "team kernel")
         kernel_desc = ("%s: ONE launch per step transforms all %d transforms, a whole transform per team of "
                        "%d CUs of one XCD (256 workgroups = %d teams, %d 64 KiB tiles per workgroup and step); the %d multi-pass launches "
                        "queued behind it as its fallback return at once" % (team_src, batch, team_cus, 256 // team_cus, info.team_tiles, launches))
