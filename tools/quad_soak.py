@@ -1,5 +1,6 @@
 """Soak of the team kernels' protocol: many executes per size, every transform of every execute compared bit for bit with the first
-(verified) result.  python tools/quad_soak.py [iterations]   (default policy: dynamic claims, both window protocols, teams of 1 ... 32)"""
+(verified) result.  python tools/quad_soak.py [iterations]   (default policy: dynamic claims, every exchange protocol, teams of 1 ... 32;
+SOAK_FULL=1: the full batches of n = 2^20, 2^18, 2^19)"""
 import os
 import sys
 import time
@@ -18,6 +19,8 @@ def main():
     fftlib.init()
     cases = [(20, 64, np.complex64), (19, 128, np.complex64), (18, 256, np.complex64), (17, 512, np.complex64), (16, 1024, np.complex64),
              (15, 2048, np.complex64), (14, 2048, np.complex128), (15, 1024, np.complex128), (16, 512, np.complex128), (19, 64, np.complex128)]
+    if os.environ.get("SOAK_FULL"):  # the BASELINE batches of the three sizes on the pair protocol (4 / 2 / 4 GiB per execute)
+        cases = [(20, 512, np.complex64), (18, 1024, np.complex64), (19, 1024, np.complex64)]
     for log2n, batch, dtype in cases:
         n = 1 << log2n
         x8 = O.gen_lcg(n, 11 + log2n, 8).astype(dtype)
