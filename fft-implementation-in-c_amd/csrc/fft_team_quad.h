@@ -47,7 +47,8 @@
 // round 3 (-10 %: 256 waves per XCD queue behind the result stores; the index now rides on the team wait's poll, see `pub`).
 // Kept although within the noise (profiles/r3_ab_early_prefetch.txt: +0.5 % at 2^20, +1 % at 2^18 / 2^16): the next transform's first two
 // chunks are requested as soon as their LDS images are free (QUAD_EARLY_CHUNK0 / 1) -- the result stores, not the request time, hold them up.
-// Team t of the eight started t * 2.5 ... 10 us late, so that the XCDs' column steps do not meet in HBM: no difference (profiles/r3_ab_stagger.txt).
+// Team t of the eight started t * 2.5 ... 10 us late, so that the XCDs' column steps do not meet in HBM: no difference (profiles/r3_ab_stagger.txt; again on
+// the pair protocol, t * 4.9 / 10 us: profiles/r4_ab_stagger.txt).
 #ifndef QUAD_LDS_SINGLE  // 1: the stage exchanges use single ds_read_b64 / ds_write_b64 (FFT_LDS_LD64 / ST64), never the fused forms (+5 %)
 #define QUAD_LDS_SINGLE 1
 #endif
